@@ -1,0 +1,86 @@
+"""Load tests/golden/*.npz and rebuild the exact inputs (stored arrays or portable PRNG)."""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+
+from quantizedsae_amd import synthetic as S
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+class Fixture:
+    def __init__(self, name: str):
+        self.name = name
+        z = np.load(GOLDEN / f"{name}.npz")
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.arrays = {k: z[k] for k in z.files if k != "meta"}
+
+    def __getitem__(self, k):
+        return self.arrays[k]
+
+    def __contains__(self, k):
+        return k in self.arrays
+
+    # -- inputs -------------------------------------------------------------
+    def x(self) -> np.ndarray:
+        m = self.meta
+        if "x" in self.arrays:
+            return self.arrays["x"]
+        return S.activations(m["seed"], m["B"], m["D"])
+
+    def state_dict(self) -> dict:
+        m = self.meta
+        v = m["variant"]
+        if v == "binary":
+            sd = S.binary_sae_params(m["seed"], m["D"], m["H"], m["n_bits"], logit_mag=m["logit_mag"],
+                                     enc_bias_std=m["enc_bias_std"], dec_bias_std=m["dec_bias_std"])
+        elif v == "baseline":
+            sd = S.baseline_sae_params(m["seed"], m["D"], m["H"], bias_std=m["bias_std"])
+        elif v == "ternary":
+            sd = S.ternary_sae_params(m["seed"], m["D"], m["H"], w_std=m["w_std"])
+        elif v == "matryoshka":
+            if m.get("edge"):
+                assert "sd.decoder.weight" in self.arrays
+                sd = {k[3:]: a for k, a in self.arrays.items() if k.startswith("sd.")}
+                return sd
+            sd = S.matryoshka_sae_params(m["seed"], m["D"], m["H"], enc_bias_shift=m["enc_bias_shift"],
+                                         min_abs=m["min_abs"], bias_std=m["bias_std"])
+        elif v == "residual":
+            sd = {}
+            for i, hdim in enumerate(m["hidden_dims"]):
+                sub = S.matryoshka_sae_params(m["seed"], m["D"], hdim, enc_bias_sigmas=-1.5,
+                                              bias_std=(0.3 if i == 0 else 0.0), stream0=100 * (i + 1))
+                for k_, a in sub.items():
+                    sd[f"saes.{i}.{k_}"] = a
+        else:
+            raise KeyError(v)
+        # stored arrays (when present) must equal the regenerated ones: the PRNG is the recipe
+        for k, a in self.arrays.items():
+            if k.startswith("sd."):
+                assert np.array_equal(sd[k[3:]], a), f"{self.name}: PRNG drifted for {k}"
+        if "dec_bits" in self.arrays:
+            bits = np.unpackbits(self.arrays["dec_bits"], axis=1)[:, : m["D"] * m["n_bits"]]
+            assert np.array_equal(bits, (sd["decoder.weight"] > 0).astype(np.uint8))
+        return sd
+
+
+def rel_err(a: np.ndarray, ref: np.ndarray) -> float:
+    """max |a-ref| / max |ref|  (the 'relative on fp32 reconstructions' tolerance of north_star)."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(a - ref)) / max(np.max(np.abs(ref)), 1e-30))
+
+
+def row_rel_err(a: np.ndarray, ref: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.max(np.abs(a - ref), axis=-1) / np.maximum(np.max(np.abs(ref), axis=-1), 1e-30)
+
+
+# near-tie audit threshold for top-k index-set parity against the reference:
+# the reference's sgemm summation order moves a latent by <= ~7e-7 at sigma ~0.18; rows whose
+# k/(k+1) gap is below NEAR_TIE_EPS may legitimately select a different boundary element.
+NEAR_TIE_EPS = 4e-6

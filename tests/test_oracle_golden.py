@@ -1,0 +1,159 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself
+(tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import Fixture, NEAR_TIE_EPS, rel_err, row_rel_err
+
+RECON_TOL = 1e-5   # north_star: within 1e-5 relative on fp32 reconstructions
+
+
+def _check_topk_sets(fx, idx, scale=1.0):
+    """Index sets equal to the reference's torch.topk on every row that is not a near-tie."""
+    got = np.sort(idx[: fx.meta["rows"]], axis=1)
+    want = fx["topk_idx"]
+    same = (got == want).all(axis=1)
+    gap = fx["gap"]
+    bad = ~same & (gap > NEAR_TIE_EPS * scale)
+    assert not bad.any(), f"{fx.name}: rows {np.nonzero(bad)[0][:8]} differ with gap {gap[bad][:8]}"
+    # rows that differ must differ in exactly the boundary element(s)
+    for r in np.nonzero(~same)[0]:
+        assert len(set(got[r]) ^ set(want[r])) <= 2
+    return int((~same).sum())
+
+
+@pytest.mark.parametrize("name", ["binary_small", "binary_n8", "binary_n2", "binary_mid",
+                                  "binary_full_g4", "binary_full_g15"])
+def test_binary_forward_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    sd = fx.state_dict()
+    rows = m["rows"]
+    x = fx.x()[:rows]
+    out = oracle.binary_forward(x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                sd["decoder.bias"], n_bits=m["n_bits"], gamma=m["gamma"], k=m["k"])
+    nties = _check_topk_sets(fx, out["idx"])
+    # values of the kept entries (ordered by index) agree to fp32 summation-order noise
+    order = np.argsort(out["idx"], axis=1)
+    val_by_idx = np.take_along_axis(out["val"], order, axis=1)
+    ok_rows = (np.sort(out["idx"], axis=1) == fx["topk_idx"]).all(axis=1)
+    assert np.max(np.abs(val_by_idx[ok_rows] - fx["topk_val_sorted_by_idx"][ok_rows])) < 4e-6
+    errs = row_rel_err(out["reconstruction"], fx["reconstruction"])
+    assert errs[ok_rows].max() < RECON_TOL, errs.max()
+    assert out["polarize_loss"] == pytest.approx(float(fx["polarize_loss"]), rel=2e-5, abs=1e-18)
+    if "int_weights" in fx:
+        packed = oracle.pack_binary(sd["decoder.weight"], m["D"], m["n_bits"])
+        assert np.array_equal(oracle.unpack_binary(packed, m["D"], m["n_bits"]), fx["int_weights"].astype(np.float32))
+    if "sparse_latent" in fx and nties == 0:
+        assert np.max(np.abs(out["latent"] - fx["sparse_latent"])) < 4e-6
+        assert np.array_equal(out["latent"] != 0, fx["sparse_latent"] != 0)
+    if rows == m["B"] and nties == 0:
+        mse = oracle.sq_err_sum(out["reconstruction"], x) / x.size
+        assert mse == pytest.approx(float(fx["mse"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", ["baseline_small", "baseline_mid", "baseline_full"])
+def test_baseline_forward_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    sd = fx.state_dict()
+    x = fx.x()[: m["rows"]]
+    out = oracle.baseline_forward(x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                  sd["decoder.bias"], k=m["k"])
+    _check_topk_sets(fx, out["idx"])
+    ok_rows = (np.sort(out["idx"], axis=1) == fx["topk_idx"]).all(axis=1)
+    errs = row_rel_err(out["reconstruction"], fx["reconstruction"])
+    assert errs[ok_rows].max() < RECON_TOL, errs.max()
+    if "sparse_latent" in fx and ok_rows.all():
+        assert np.max(np.abs(out["latent"] - fx["sparse_latent"])) < 4e-6
+
+
+@pytest.mark.parametrize("name", ["ternary_small", "ternary_mid"])
+def test_ternary_forward_matches_reference(name):
+    fx = Fixture(name)
+    sd = fx.state_dict()
+    out = oracle.ternary_forward(fx.x(), sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"])
+    assert float(fx["nonzero_code_fraction"]) > 0.2          # fixture exercises non-zero codes
+    assert np.max(np.abs(out["latent"] - fx["latent"])) < 4e-6
+    assert np.array_equal(out["latent"] > 0, fx["latent"] > 0) or \
+        np.abs(fx["latent"][(out["latent"] > 0) != (fx["latent"] > 0)]).max() < 1e-6
+    assert rel_err(out["reconstruction"], fx["reconstruction"]) < RECON_TOL
+
+
+@pytest.mark.parametrize("name", ["matryoshka_small", "matryoshka_edge", "matryoshka_mid", "matryoshka_full"])
+def test_matryoshka_forward_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    sd = fx.state_dict()
+    assert oracle.matryoshka_sizes(m["H"], m["n_bits"]) == m["sizes"]
+    out = oracle.matryoshka_forward(fx.x(), sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                    sd["decoder.weight_mirror"], sd["decoder.bias"], n_bits=m["n_bits"],
+                                    abs_range=m["abs_range"])
+    want_bits = np.unpackbits(fx["zbits"], axis=1)[:, : m["H"]]
+    assert want_bits.sum() > 0
+    assert np.array_equal(out["zbits"], want_bits)           # integer work: bit-exact
+    np.testing.assert_allclose(out["latent_groups"], fx["latent_groups"], rtol=1e-6)
+    for lvl in range(m["n_bits"]):
+        assert rel_err(out["reconstruction_levels"][lvl], fx["reconstruction_levels"][lvl]) < RECON_TOL, lvl
+
+
+@pytest.mark.parametrize("name", ["residual_small", "residual_mid"])
+def test_residual_forward_matches_reference(name):
+    fx = Fixture(name)
+    m = fx.meta
+    sd = fx.state_dict()
+    stages = [dict(enc_w=sd[f"saes.{i}.encoder.0.weight"], enc_b=sd[f"saes.{i}.encoder.0.bias"],
+                   dec_w=sd[f"saes.{i}.decoder.weight"], dec_wm=sd[f"saes.{i}.decoder.weight_mirror"],
+                   dec_bias=sd[f"saes.{i}.decoder.bias"]) for i in range(m["n_bits"])]
+    out = oracle.residual_forward(fx.x(), stages, abs_range=m["abs_range"])
+    np.testing.assert_allclose(out["latent_groups"], fx["latent_groups"], rtol=2e-3)
+    for lvl in range(m["n_bits"]):
+        assert rel_err(out["reconstruction_levels"][lvl], fx["reconstruction_levels"][lvl]) < 5e-4, lvl
+
+
+def test_sigmoid_cutoffs_pinned():
+    """The fp32 cutoffs hard-coded in the oracle/kernels are the ones measured on torch.sigmoid."""
+    fx = Fixture("sigmoid_cutoffs")
+    gt, ge = oracle.sigmoid_cutoffs()
+    assert np.float32(gt).view(np.uint32) == fx["gt_cutoff_bits"]
+    assert np.float32(ge).view(np.uint32) == fx["ge_cutoff_bits"]
+    import torch
+    for w, want_gt, want_ge in [(gt, True, True), (np.nextafter(gt, np.float32(-1)), False, True),
+                                (ge, False, True), (np.nextafter(ge, np.float32(-1)), False, False)]:
+        s = torch.sigmoid(torch.full((16,), float(w), dtype=torch.float32))
+        assert bool((s > 0.5).all()) == want_gt and bool((s >= 0.5).all()) == want_ge
+
+
+# --- known-answer micro tests lifted from the reference's semantics ---
+def test_bit_layout_known_answers():
+    # binary.py:28-35: column d*n+b is bit b (LSB first), MSB negative: (1,0,1,0)->5 ; (0,1,0,1)->-6
+    L = 30.0
+    logits = np.array([[L, -L, L, -L, -L, L, -L, L]], dtype=np.float32)   # H=1, D=2, n=4
+    packed = oracle.pack_binary(logits, 2, 4)
+    assert oracle.unpack_binary(packed, 2, 4).tolist() == [[5.0, -6.0]]
+    # README.md:100 worked example: -6 at gamma=4, n=4 -> step 0.5 -> -3.0
+    rec = oracle.decode_binary(np.array([[0]], np.int32), np.array([[1.0]], np.float32), packed, 2, 4, 0.5)
+    assert rec.tolist() == [[2.5, -3.0]]
+
+
+def test_level_sizes_and_scales_known_answers():
+    assert oracle.matryoshka_sizes(32768, 4) == [4096, 4096, 8192, 16384]
+    assert oracle.matryoshka_sizes(32768, 1) == [32768]
+    H, D = 32, 16
+    w = np.ones((H, D), np.float32)
+    for abs_range, want in [(4.0, [2.0, 1.0, 0.5, 0.25]), (1.5, [0.75, 0.375, 0.1875, 0.09375])]:
+        codes, scale = oracle.matryoshka_pack(w, w, 4, abs_range)
+        sizes = oracle.matryoshka_sizes(H, 4)
+        assert (codes == 2).all()
+        norm = np.float32(np.sqrt(np.float32(4 * D)))
+        starts = np.cumsum([0] + sizes[:-1])
+        for s, f in zip(starts, want):
+            assert scale[s] == np.float32(1.0) / norm * np.float32(f)
+
+
+def test_topk_order_and_ties():
+    lat = np.array([[1, 1, 1, 1, .5], [0, 0, 0, 0, 0], [np.nan, 3, -1, np.inf, 2]], dtype=np.float32)
+    idx, val = oracle.topk(lat, 2)
+    assert idx.tolist() == [[0, 1], [0, 1], [0, 3]]      # (value desc, index asc); NaN ranks first
+    assert int(32768 * 0.002) == 65 and np.float32(4.0 / 2 ** 3) == 0.5
