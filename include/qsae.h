@@ -1,0 +1,151 @@
+/*
+ * qsae.h -- C ABI of the MI355X (gfx950) quantized-SAE forward backend.
+ *
+ * Drop-in boundary for the forward hot path of ASSERT-KTH/QuantizedSAE.  The reference
+ * is pure Python/PyTorch and has no FFI of its own; each entry
+ * point below replaces the ATen call sequence cited next to it (paths relative to the
+ * reference root).  Everything here is stateless: plain device pointers and sizes, no
+ * torch types, work is enqueued on the given HIP stream and the call returns without
+ * synchronising.  The Python host side in quantizedsae_amd/ binds these with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - all tensors row-major, contiguous, device memory unless stated;
+ *   - B rows of activations, D = input_dim, H = hidden_dim, k = top-k;
+ *   - return value: QSAE_OK or a negative QSAE_ERR_* code; qsae_last_error() gives text;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - B == 0 is a valid no-op everywhere.
+ *
+ * Numerical contract (bit-exact against oracle/qsae_oracle.c):
+ *   encoder latent = fp32 fmaf chain over k ascending seeded with bias (what
+ *   v_mfma_f32_32x32x2_f32 computes when K is walked in order); top-k = k largest by
+ *   (value desc, index asc), NaN above +inf; sparse decode = ascending-index fmaf chain,
+ *   then separately rounded *step and +bias.
+ */
+#ifndef QSAE_H
+#define QSAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QSAE_ABI_VERSION 1
+
+#define QSAE_OK 0
+#define QSAE_ERR_INVALID_ARG (-1)  /* null pointer, non-positive dim, misaligned pointer      */
+#define QSAE_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels implement                 */
+#define QSAE_ERR_HIP (-3)          /* a HIP runtime call failed (text in qsae_last_error())    */
+#define QSAE_ERR_WORKSPACE (-4)    /* workspace too small; see the *_workspace_bytes() helpers */
+
+/* activation applied by qsae_encode_dense */
+#define QSAE_ACT_NONE 0    /* BinarySAE / Baseline: sae/binary.py:82-84, sae/baseline.py:8-10 */
+#define QSAE_ACT_RELU 1    /* Ternary: sae/ternary.py:95-98                                    */
+#define QSAE_ACT_SIGMOID 2 /* Matryoshka: sae/quantized_matryoshka.py:206-209                  */
+
+typedef void* qsae_stream_t;
+
+/* -- library ---------------------------------------------------------------------------- */
+int qsae_abi_version(void);
+/* Thread-local text of the last failing call ("" if none). */
+const char* qsae_last_error(void);
+/* Properties of the current device: compute units, name of the gfx target (e.g. "gfx950"). */
+int qsae_device_info(int* cu_count, char* arch, int arch_len);
+
+/* -- encoder ---------------------------------------------------------------------------- */
+/* out[b][h] = act(bias[h] + sum_k x[b][k] * W[h][k])           (fp32 MFMA, exact fmaf chain)
+ * Replaces nn.Linear (+ReLU / +Sigmoid) in SparseAutoencoder.encode, sae/base.py:16-19.
+ * x [B][D], W [H][D], bias [H] or NULL, out [B][out_ld] with out_ld >= H.
+ * Requires D % 4 == 0 and 16-byte aligned x, W. */
+int qsae_encode_dense(const float* x, const float* W, const float* bias, int B, int D, int H,
+                      int act, float* out, int64_t out_ld, qsae_stream_t stream);
+
+/* zbits[b][w] bit j = (sigmoid(pre[b][32w+j]) > 0.5) == (pre >= 0x33C00001), pre as above.
+ * Replaces encoder(x) followed by `latent > 0.5`, sae/quantized_matryoshka.py:97-99,206-209
+ * (also scripts/analysis/dynamic_analysis.py:51).  zbits [B][words_ld] uint32, words_ld >=
+ * ceil(H/32); bits beyond H are zero. */
+int qsae_encode_bits(const float* x, const float* W, const float* bias, int B, int D, int H,
+                     uint32_t* zbits, int64_t words_ld, qsae_stream_t stream);
+
+/* Per-row top-k of a dense latent [B][ld]: idx/val [B][k] ordered by (value desc, index asc).
+ * If zero_rest != 0 every non-selected entry of `latent` is overwritten with +0 in place, which
+ * yields `latent * mask` of sae/binary.py:94-99 and the scatter of sae/baseline.py:34-40.
+ * Replaces torch.topk + zeros_like + scatter_.  1 <= k <= min(H, 256), H <= 32768. */
+int qsae_topk_rows(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val,
+                   int zero_rest, qsae_stream_t stream);
+
+/* Fused encoder + top-k without materialising the dense latent: same results as
+ * qsae_encode_dense(act=NONE) followed by qsae_topk_rows.  Workspace from
+ * qsae_encode_topk_workspace_bytes(). */
+size_t qsae_encode_topk_workspace_bytes(int B, int D, int H, int k);
+int qsae_encode_topk(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
+                     int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
+                     qsae_stream_t stream);
+
+/* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
+int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
+                 qsae_stream_t stream);
+
+/* -- BinarySAE decoder (sae/binary.py:10-69) ---------------------------------------------- */
+/* Bytes per packed dictionary row: D fields of width fw = 1,2,4,8 (smallest power of two >=
+ * n_bits), rounded up to a multiple of 4 bytes. */
+int qsae_binary_row_bytes(int D, int n_bits);
+/* Hard two's-complement packer == binary_decoder.quantized_int_weights(), sae/binary.py:49-58:
+ * bit = sigmoid(logit) > 0.5; logits [H][D*n_bits] (column d*n+b = bit b of output d, LSB first,
+ * MSB negative) -> packed [H][row_bytes], fields little-endian.  If polarize_sum != NULL the
+ * device double receives sum(p(1-p)2^b) (sae/binary.py:42-43; caller divides by H*D*n). */
+int qsae_pack_binary(const float* logits, int H, int D, int n_bits, uint8_t* packed,
+                     double* polarize_sum, qsae_stream_t stream);
+/* int_weights[h][d] as fp32 (for decoder_dictionary(), inference/framework.py:114-124). */
+int qsae_unpack_binary(const uint8_t* packed, int H, int D, int n_bits, float* int_weights,
+                       qsae_stream_t stream);
+/* recon[b][d] = step * sum_j val[b][j] * w[idx[b][j]][d] + bias[d]  -- the reference's dense
+ * `latent.matmul(int_weights)` (sae/binary.py:38) evaluated on the k non-zeros only. */
+int qsae_decode_binary_sparse(const int32_t* idx, const float* val, int B, int k,
+                              const uint8_t* packed, int H, int D, int n_bits, float step,
+                              const float* bias, float* recon, qsae_stream_t stream);
+/* Same with an fp32 table [H][D]: Baseline decoder nn.Linear(H, D) (sae/baseline.py:12,29; the
+ * table is decoder.weight transposed) and BinarySAE's "soft" int_weights for unpolarised
+ * checkpoints (sae/binary.py:26-38).  scale == 1 skips the multiply. */
+int qsae_decode_table_sparse(const int32_t* idx, const float* val, int B, int k, const float* table,
+                             int H, int D, float scale, const float* bias, float* recon,
+                             qsae_stream_t stream);
+/* Soft int_weights table of sae/binary.py:26-35: table[h][d] = sum_b sigmoid(logit)*bw[b]. */
+int qsae_binary_soft_table(const float* logits, int H, int D, int n_bits, float* table,
+                           qsae_stream_t stream);
+
+/* -- Ternary decoder (sae/ternary.py:41-52) ---------------------------------------------- */
+/* codes2 [D][ceil(H/16)] uint32: 2-bit fields, 0 -> 0, 1 -> +1, 3 -> -1 (two's complement),
+ * hard = sign(w) * (|w| >= 0.5); w is decoder.weight [D][H]. */
+int qsae_pack_ternary(const float* w, int D, int H, uint32_t* codes2, qsae_stream_t stream);
+/* recon[b][d] = sum_h h[b][h] * hard[d][h]   (no bias), h [B][ld]. */
+int qsae_decode_ternary_dense(const float* h, int64_t ld, int B, int H, const uint32_t* codes2, int D,
+                              float* recon, qsae_stream_t stream);
+
+/* -- Matryoshka decoder (sae/quantized_matryoshka.py:10-143) ------------------------------ */
+/* level sizes of :25-38; sizes[n_bits]. Host-side helper. */
+int qsae_matryoshka_sizes(int H, int n_bits, int32_t* sizes);
+/* codes2t [D][ceil(H/16)] uint32 2-bit two's-complement fields of S/2 in {-1,0,+1} where
+ * S = sgn(sig(w)>=.5)+sgn(sig(wm)>=.5) (:67-80), transposed so that H is contiguous;
+ * scale[j] = reciprocal(||S_j||+1e-8) * 2^(n-i-2) * abs_range/2^(n-1) for j in level i (:82-90). */
+int qsae_pack_matryoshka(const float* w, const float* wm, int H, int D, int n_bits, float abs_range,
+                         uint32_t* codes2t, float* scale, qsae_stream_t stream);
+/* levels[i][b][d] cumulative reconstructions (:121-129), l0_counts[i] = number of set z bits in
+ * level i over the whole batch (latent_group[i] = l0_counts[i] / B, :128).
+ * zbits as produced by qsae_encode_bits. */
+int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
+                           const uint32_t* codes2t, const float* scale, const float* bias,
+                           int allow_bias, float* levels, unsigned long long* l0_counts,
+                           qsae_stream_t stream);
+
+/* -- metric ------------------------------------------------------------------------------ */
+/* *sum += sum_i (float)((recon[i]-x[i])^2) accumulated in double (device pointer; the caller
+ * zeroes it).  scripts/analysis/dynamic_analysis.py:86-100. */
+int qsae_sq_err_sum(const float* recon, const float* x, size_t n, double* sum, qsae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSAE_H */

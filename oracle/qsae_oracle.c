@@ -169,10 +169,10 @@ void qsae_oracle_densify(const int32_t* idx, const float* val, int B, int k, int
 /* BinarySAE decoder packer (binary.py:49-58): hard bit = sigmoid(logit) > 0.5,
  * column d*n+b is bit b (LSB first) of output d, MSB weight negative (two's complement).
  * Storage: field width fw = 1,2,4,8 (smallest power of two >= n), fields little-endian
- * inside each byte, row h contiguous: packed[h][D*fw/8].  The field holds the n-bit
- * two's-complement code (upper fw-n bits zero). */
+ * inside each byte, row h contiguous: packed[h][row_bytes], row_bytes = D*fw/8 rounded up
+ * to a multiple of 4.  The field holds the n-bit two's-complement code (upper fw-n bits zero). */
 static int field_width(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : 8; }
-int qsae_oracle_binary_row_bytes(int D, int n) { return (D * field_width(n) + 7) / 8; }
+int qsae_oracle_binary_row_bytes(int D, int n) { return ((D * field_width(n) + 31) / 32) * 4; }
 
 void qsae_oracle_pack_binary(const float* logits, int H, int D, int n, uint8_t* packed) {
     const int fw = field_width(n), rb = qsae_oracle_binary_row_bytes(D, n);

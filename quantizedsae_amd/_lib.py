@@ -1,0 +1,81 @@
+"""ctypes binding of the C ABI in include/qsae.h (libqsae_hip.so).
+
+This is the only way the package reaches the GPU kernels; there is no CPU or eager-PyTorch
+fallback.  If the library is missing or fails to load, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libqsae_hip.so"
+
+OK = 0
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/qsae.h
+SIGNATURES = {
+    "qsae_abi_version": (_i, []),
+    "qsae_last_error": (C.c_char_p, []),
+    "qsae_device_info": (_i, [C.POINTER(_i), C.c_char_p, _i]),
+    "qsae_encode_dense": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "qsae_encode_bits": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "qsae_topk_rows": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "qsae_encode_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "qsae_encode_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "qsae_densify": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "qsae_binary_row_bytes": (_i, [_i, _i]),
+    "qsae_pack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "qsae_unpack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "qsae_decode_binary_sparse": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "qsae_decode_table_sparse": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "qsae_binary_soft_table": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "qsae_pack_ternary": (_i, [_vp, _i, _i, _vp, _vp]),
+    "qsae_decode_ternary_dense": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
+    "qsae_matryoshka_sizes": (_i, [_i, _i, _vp]),
+    "qsae_pack_matryoshka": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "qsae_decode_matryoshka": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "qsae_sq_err_sum": (_i, [_vp, _vp, _sz, _vp, _vp]),
+}
+
+
+class QsaeError(RuntimeError):
+    """A libqsae_hip call returned a non-zero status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libqsae_hip error {code}: {message}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libqsae_hip.so (once).  Raises RuntimeError if it is missing -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m quantizedsae_amd.build` "
+            "(hipcc --offload-arch=gfx950).  quantizedsae_amd has no CPU / eager fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here means the library is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.qsae_abi_version() != 1:
+        raise RuntimeError("libqsae_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != OK:
+        msg = load().qsae_last_error()
+        raise QsaeError(code, msg.decode(errors="replace") if msg else "")

@@ -1,0 +1,74 @@
+// common.h -- shared helpers for the gfx950 quantized-SAE kernels (host + device).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/qsae.h"
+
+namespace qsae {
+
+// ---- error plumbing -----------------------------------------------------------------
+char* last_error_buf();   // thread-local, 512 bytes (defined in api_misc.hip)
+
+inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+    snprintf(last_error_buf(), 512, fmt, a, b, c);
+    return code;
+}
+
+#define QSAE_CHECK_ARG(cond, what)                                                         \
+    do {                                                                                   \
+        if (!(cond)) return ::qsae::fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: " what, __func__); \
+    } while (0)
+
+#define QSAE_CHECK_SUPPORTED(cond, what)                                                   \
+    do {                                                                                   \
+        if (!(cond)) return ::qsae::fail(QSAE_ERR_UNSUPPORTED, "%s: unsupported: " what, __func__); \
+    } while (0)
+
+#define QSAE_HIP(call)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf(::qsae::last_error_buf(), 512, "%s: %s failed: %s", __func__, #call,  \
+                     hipGetErrorString(e_));                                               \
+            return QSAE_ERR_HIP;                                                           \
+        }                                                                                  \
+    } while (0)
+
+#define QSAE_LAUNCH_CHECK() QSAE_HIP(hipGetLastError())
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline hipStream_t as_stream(qsae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device helpers -----------------------------------------------------------------
+// fp32 cutoffs of the reference's sigmoid (see oracle/qsae_oracle.c header):
+//   sigmoid(w) >  0.5  <=>  w >= 0x33C00001 ;  sigmoid(w) >= 0.5  <=>  w >= 0xB43FFFFE
+#define QSAE_SIG_GT_BITS 0x33C00001u
+#define QSAE_SIG_GE_BITS 0xB43FFFFEu
+
+__device__ __forceinline__ bool sig_gt_half(float w) { return w >= __uint_as_float(QSAE_SIG_GT_BITS); }
+__device__ __forceinline__ bool sig_ge_half(float w) { return w >= __uint_as_float(QSAE_SIG_GE_BITS); }
+
+// Monotone map float -> uint32 (larger float -> larger key); NaN above +inf; -0 == +0.
+__device__ __forceinline__ uint32_t mono_key(float v) {
+    uint32_t u = __float_as_uint(v);
+    if (v != v) return 0xFFFFFFFFu;
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// Total order of the top-k: larger key wins; ties in value go to the smaller index.
+__device__ __forceinline__ unsigned long long full_key(float v, uint32_t idx) {
+    return (static_cast<unsigned long long>(mono_key(v)) << 32) | static_cast<uint32_t>(~idx);
+}
+__device__ __forceinline__ uint32_t key_index(unsigned long long key) {
+    return ~static_cast<uint32_t>(key & 0xFFFFFFFFull);
+}
+
+__host__ __device__ inline int field_width(int n_bits) {
+    return n_bits <= 1 ? 1 : n_bits <= 2 ? 2 : n_bits <= 4 ? 4 : 8;
+}
+
+}  // namespace qsae

@@ -1,0 +1,333 @@
+// dense_dec.hip -- dense quantized-dictionary decoders (ternary, matryoshka).
+//
+// Ternary (reference sae/ternary.py:41-52): recon = h @ hard^T with hard = sign(w)*(|w|>=0.5)
+// in {-1,0,+1}; the reference materialises three [D,H] fp32 temporaries per call.  Here the
+// dictionary is packed once to 2-bit fields (4 MiB at 512x32768) and expanded to fp32 inside
+// the LDS staging of the exact-fp32 MFMA contraction (gemm_mfma_f32.h).
+//
+// Matryoshka (reference sae/quantized_matryoshka.py:47-143): per nested level i,
+// recon += (scale * z) @ S with z in {0,1}, S = Bsign + Bsign_mirror in {-2,0,2} and a per-row
+// scale.  Packed as 2-bit fields of S/2 (transposed, hidden index contiguous) plus fp32
+// 2*scale; all levels run in ONE K-walk whose accumulator is written out at every level
+// boundary (the reference launches one GEMM per level and clones the running sum).
+#include "gemm_mfma_f32.h"
+
+namespace qsae {
+
+constexpr int kMaxLevels = 8;
+
+// ---- ternary --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_ternary_kernel(const float* __restrict__ w, int D, int H, int words, uint32_t* __restrict__ codes) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(D) * words) return;
+    const int d = static_cast<int>(gid / words), wi = static_cast<int>(gid % words);
+    const float* row = w + static_cast<long long>(d) * H;
+    uint32_t word = 0;
+    for (int f = 0; f < 16; ++f) {
+        const int h = wi * 16 + f;
+        if (h >= H) break;
+        const float x = row[h];
+        const uint32_t code = (fabsf(x) >= 0.5f) ? (x > 0.0f ? 1u : 3u) : 0u;   // ternary.py:47-49
+        word |= code << (2 * f);
+    }
+    codes[gid] = word;
+}
+
+template <int BM, int BN>
+struct EpiStore {
+    static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
+    static constexpr int kCheckpoints = 0;
+    struct Args {
+        float* out;
+        int64_t ld;
+    };
+    __device__ __forceinline__ void init(const Args&, f32x16 (&acc)[MT][NT], const TileCtx&) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    }
+    __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c, float*) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                if (row >= c.M) continue;
+                float* orow = a.out + static_cast<int64_t>(row) * a.ld;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+                    if (col < c.N) orow[col] = acc[mt][nt][r];
+                }
+            }
+    }
+};
+
+// ---- matryoshka -----------------------------------------------------------------------------
+struct LevelTable {
+    int n;
+    int end[kMaxLevels];     // exclusive end (hidden index) of each level
+    float factor[kMaxLevels];  // 2^(n-i-2) * quant_step
+};
+
+// codes2t[d][h/16] field = S/2 in two's complement, S = sgn(sig(w)>=.5) + sgn(sig(wm)>=.5)
+__global__ void __launch_bounds__(256)
+pack_matryoshka_codes_kernel(const float* __restrict__ w, const float* __restrict__ wm, int H, int D, int words,
+                             uint32_t* __restrict__ codes) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(D) * words) return;
+    const int d = static_cast<int>(gid / words), wi = static_cast<int>(gid % words);
+    uint32_t word = 0;
+    for (int f = 0; f < 16; ++f) {
+        const int h = wi * 16 + f;
+        if (h >= H) break;
+        const long long o = static_cast<long long>(h) * D + d;
+        const int half = (sig_ge_half(w[o]) ? 1 : -1) + (sig_ge_half(wm[o]) ? 1 : -1);   // -2, 0, 2
+        const uint32_t code = half == 0 ? 0u : (half > 0 ? 1u : 3u);
+        word |= code << (2 * f);
+    }
+    codes[gid] = word;
+}
+
+// scale[j] = reciprocal(sqrt(4*nz_j) + 1e-8) * factor(level(j)); one wave per hidden row.
+__global__ void __launch_bounds__(256)
+pack_matryoshka_scale_kernel(const float* __restrict__ w, const float* __restrict__ wm, int H, int D,
+                             LevelTable lv, float* __restrict__ scale) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= H) return;
+    int nz = 0;
+    for (int d = lane; d < D; d += 64) {
+        const long long o = static_cast<long long>(j) * D + d;
+        nz += (sig_ge_half(w[o]) != sig_ge_half(wm[o])) ? 0 : 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) nz += __shfl_down(nz, off, 64);
+    if (lane == 0) {
+        int level = 0;
+        while (level < lv.n - 1 && j >= lv.end[level]) ++level;
+        const float norm = sqrtf(static_cast<float>(4 * nz));
+        const float denom = norm + 1e-8f;
+        const float rcp = 1.0f / denom;
+        scale[j] = rcp * lv.factor[level];
+    }
+}
+
+template <int BM, int BN>
+struct EpiLevels {
+    static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
+    static constexpr int kCheckpoints = 1;
+    struct Args {
+        LevelTable lv;
+        const float* bias;     // nullptr when allow_bias == 0
+        float* levels;         // [n][B][D]
+        int64_t level_stride;  // B * D
+    };
+    __device__ __forceinline__ void init(const Args&, f32x16 (&acc)[MT][NT], const TileCtx&) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    }
+    __device__ __forceinline__ void write_level(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c,
+                                                int level) const {
+        float* base = a.levels + static_cast<int64_t>(level) * a.level_stride;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+            if (col >= c.N) continue;
+            const float b = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                    if (row < c.M) base[static_cast<int64_t>(row) * c.N + col] = acc[mt][nt][r] + b;
+                }
+        }
+    }
+    __device__ __forceinline__ void checkpoint(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c,
+                                               int k_done) const {
+        // level boundaries are multiples of BK (checked on the host), so every boundary coincides
+        // with the end of exactly one K slice; empty levels share a boundary and are all written.
+        for (int i = 0; i < a.lv.n; ++i)
+            if (a.lv.end[i] == k_done) write_level(a, acc, c, i);
+    }
+    __device__ __forceinline__ void finish(const Args&, f32x16 (&)[MT][NT], const TileCtx&, float*) {}
+};
+
+// l0_counts[level] += popcount of the level's z bits (level boundaries multiples of 32)
+__global__ void __launch_bounds__(256)
+count_bits_kernel(const uint32_t* __restrict__ zbits, int64_t words_ld, int B, int words, LevelTable lv,
+                  unsigned long long* __restrict__ counts) {
+    unsigned long long local[kMaxLevels] = {0};
+    const long long total = static_cast<long long>(B) * words;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const long long b = i / words;
+        const int wi = static_cast<int>(i % words);
+        const uint32_t v = zbits[b * words_ld + wi];
+        int level = 0;
+        while (level < lv.n - 1 && wi * 32 >= lv.end[level]) ++level;
+#pragma unroll
+        for (int l = 0; l < kMaxLevels; ++l) local[l] += (l == level) ? __popc(v) : 0;
+    }
+    for (int l = 0; l < lv.n; ++l) {
+        unsigned long long v = local[l];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counts[l], v);
+    }
+}
+
+static int make_levels(int H, int n_bits, float abs_range, LevelTable& lv) {
+    int32_t sizes[kMaxLevels];
+    const int rc = qsae_matryoshka_sizes(H, n_bits, sizes);
+    if (rc != QSAE_OK) return rc;
+    lv.n = n_bits;
+    int acc = 0;
+    const double quant_step = static_cast<double>(abs_range) / static_cast<double>(1u << (n_bits - 1));
+    for (int i = 0; i < n_bits; ++i) {
+        acc += sizes[i];
+        lv.end[i] = acc;
+        const int e = n_bits - i - 2;
+        const double p = e >= 0 ? static_cast<double>(1u << e) : 1.0 / static_cast<double>(1u << (-e));
+        lv.factor[i] = static_cast<float>(p * quant_step);
+    }
+    for (int i = n_bits; i < kMaxLevels; ++i) { lv.end[i] = acc; lv.factor[i] = 0.0f; }
+    return QSAE_OK;
+}
+
+}  // namespace qsae
+
+using namespace qsae;
+
+extern "C" int qsae_matryoshka_sizes(int H, int n_bits, int32_t* sizes) {
+    QSAE_CHECK_ARG(H > 0 && n_bits >= 1 && n_bits <= kMaxLevels && sizes, "H > 0, 1 <= n_bits <= 8, sizes != NULL");
+    long long sum = 0;
+    for (int i = 0; i < n_bits; ++i) { sizes[i] = (i < 2) ? 1 : (1 << (i - 1)); sum += sizes[i]; }
+    if (sum != H) {
+        const double sf = static_cast<double>(H) / static_cast<double>(sum);
+        long long acc = 0;
+        for (int i = 0; i < n_bits; ++i) {
+            int s = static_cast<int>(static_cast<double>(sizes[i]) * sf);
+            sizes[i] = s < 1 ? 1 : s;
+        }
+        for (int i = 0; i < n_bits - 1; ++i) acc += sizes[i];
+        sizes[n_bits - 1] = static_cast<int32_t>(H - acc);
+    }
+    return QSAE_OK;
+}
+
+extern "C" int qsae_pack_ternary(const float* w, int D, int H, uint32_t* codes2, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(D > 0 && H > 0 && w && codes2, "D > 0, H > 0, non-null pointers");
+    const int words = (H + 15) / 16;
+    const long long total = static_cast<long long>(D) * words;
+    hipLaunchKernelGGL(pack_ternary_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w, D, H, words, codes2);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+template <int BM, int BN, int BK>
+static int run_ternary(const float* h, int64_t ld, int B, int H, const uint32_t* codes, int D, float* recon,
+                       hipStream_t s) {
+    using Epi = EpiStore<BM, BN>;
+    typename Epi::Args ea{recon, D};
+    const int64_t words = (H + 15) / 16;
+    if (H % BK == 0) {
+        using LA = LoaderF32<BM, BK, false>;
+        using LB = LoaderCode2<BN, BK, false>;
+        typename LA::Args la{h, ld, B};
+        typename LB::Args lb{codes, words, D};
+        return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, s);
+    }
+    using LA = LoaderF32<BM, BK, true>;
+    using LB = LoaderCode2<BN, BK, true>;
+    typename LA::Args la{h, ld, B};
+    typename LB::Args lb{codes, words, D};
+    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, s);
+}
+
+extern "C" int qsae_decode_ternary_dense(const float* h, int64_t ld, int B, int H, const uint32_t* codes2, int D,
+                                         float* recon, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0 && D > 0, "B >= 0, H > 0, D > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(h && codes2 && recon, "null pointer");
+    QSAE_CHECK_ARG(ld >= H, "ld < H");
+    QSAE_CHECK_SUPPORTED(H % 4 == 0 && ld % 4 == 0, "H and ld must be multiples of 4");
+    QSAE_CHECK_ARG(aligned16(h), "h must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const long long t256 = static_cast<long long>((B + 255) / 256) * ((D + 255) / 256);
+    if (t256 >= 256) return run_ternary<256, 256, 32>(h, ld, B, H, codes2, D, recon, s);
+    return run_ternary<128, 128, 32>(h, ld, B, H, codes2, D, recon, s);
+}
+
+extern "C" int qsae_pack_matryoshka(const float* w, const float* wm, int H, int D, int n_bits, float abs_range,
+                                    uint32_t* codes2t, float* scale, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(H > 0 && D > 0 && w && wm && codes2t && scale, "H > 0, D > 0, non-null pointers");
+    QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= kMaxLevels, "1 <= n_bits <= 8 required");
+    LevelTable lv;
+    const int rc = make_levels(H, n_bits, abs_range, lv);
+    if (rc != QSAE_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    const int words = (H + 15) / 16;
+    const long long total = static_cast<long long>(D) * words;
+    hipLaunchKernelGGL(pack_matryoshka_codes_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       s, w, wm, H, D, words, codes2t);
+    QSAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pack_matryoshka_scale_kernel, dim3((H + 3) / 4), dim3(256), 0, s, w, wm, H, D, lv, scale);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+template <int BM, int BN, int BK>
+static int run_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, const uint32_t* codes,
+                          const float* scale2, const typename EpiLevels<BM, BN>::Args& ea, hipStream_t s) {
+    using Epi = EpiLevels<BM, BN>;
+    using LA = LoaderBitsScale<BM, BK, false>;
+    using LB = LoaderCode2<BN, BK, false, 2>;   // fields hold S/2
+    typename LA::Args la{zbits, words_ld, B, scale2};
+    typename LB::Args lb{codes, (H + 15) / 16, D};
+    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, s);
+}
+
+extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
+                                      const uint32_t* codes2t, const float* scale, const float* bias,
+                                      int allow_bias, float* levels, unsigned long long* l0_counts,
+                                      qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0 && D > 0, "B >= 0, H > 0, D > 0 required");
+    QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= kMaxLevels, "1 <= n_bits <= 8 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(zbits && codes2t && scale && levels, "null pointer");
+    QSAE_CHECK_ARG(words_ld >= (H + 31) / 32, "words_ld < ceil(H/32)");
+    QSAE_CHECK_ARG(aligned16(scale), "scale must be 16-byte aligned");
+    LevelTable lv;
+    const int rc = make_levels(H, n_bits, 1.0f, lv);
+    if (rc != QSAE_OK) return rc;
+    QSAE_CHECK_SUPPORTED(H % 32 == 0, "H must be a multiple of 32 (pad the dictionary)");
+    for (int i = 0; i < n_bits; ++i)
+        QSAE_CHECK_SUPPORTED(lv.end[i] % 32 == 0, "level boundaries must be multiples of 32 (pad the levels)");
+    hipStream_t s = as_stream(stream);
+    if (l0_counts) {
+        QSAE_HIP(hipMemsetAsync(l0_counts, 0, sizeof(unsigned long long) * n_bits, s));
+        const int words = H / 32;
+        long long total = static_cast<long long>(B) * words;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(count_bits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, zbits, words_ld, B,
+                           words, lv, l0_counts);
+        QSAE_LAUNCH_CHECK();
+    }
+    const long long t256 = static_cast<long long>((B + 255) / 256) * ((D + 255) / 256);
+    if (t256 >= 256) {
+        typename EpiLevels<256, 256>::Args ea{lv, allow_bias ? bias : nullptr, levels, static_cast<int64_t>(B) * D};
+        return run_matryoshka<256, 256, 32>(zbits, words_ld, B, H, D, codes2t, scale, ea, s);
+    }
+    typename EpiLevels<128, 128>::Args ea{lv, allow_bias ? bias : nullptr, levels, static_cast<int64_t>(B) * D};
+    return run_matryoshka<128, 128, 32>(zbits, words_ld, B, H, D, codes2t, scale, ea, s);
+}

@@ -1,0 +1,104 @@
+// misc.hip -- library plumbing, dense-latent materialisation and the recon-MSE reduction.
+#include "common.h"
+
+namespace qsae {
+
+char* last_error_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// dense[b][idx[b][j]] = val[b][j]  (after the rows were zeroed): reference zeros_like + scatter_
+// (sae/baseline.py:38-40) and latent*mask (sae/binary.py:96-99).
+__global__ void __launch_bounds__(256)
+scatter_rows_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val, long long total, int k,
+                    int H, float* __restrict__ dense, int64_t ld) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const long long b = gid / k;
+    const int h = idx[gid];
+    if (h >= 0 && h < H) dense[b * ld + h] = val[gid];
+}
+
+// sum of (float)((r - x)^2) in double: per-thread fp32 square, double accumulation, one atomic per
+// wave (scripts/analysis/dynamic_analysis.py:86-100 accumulates a fp32 per-batch sum into a
+// Python float; double accumulation is at least as accurate).
+__global__ void __launch_bounds__(256)
+sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n, double* __restrict__ sum) {
+    const size_t n4 = n / 4;
+    double acc = 0.0;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = a[j] - b[j];
+            acc += static_cast<double>(d * d);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        const float d = r[i] - x[i];
+        acc += static_cast<double>(d * d);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(sum, acc);
+}
+
+}  // namespace qsae
+
+using namespace qsae;
+
+extern "C" int qsae_abi_version(void) { return QSAE_ABI_VERSION; }
+
+extern "C" const char* qsae_last_error(void) { return last_error_buf(); }
+
+extern "C" int qsae_device_info(int* cu_count, char* arch, int arch_len) {
+    int dev = 0;
+    QSAE_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    QSAE_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, static_cast<size_t>(arch_len) - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return QSAE_OK;
+}
+
+extern "C" int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
+                            qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0 && k >= 1, "B >= 0, H > 0, k >= 1 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(idx && val && dense, "null pointer");
+    QSAE_CHECK_ARG(ld >= H, "ld < H");
+    hipStream_t s = as_stream(stream);
+    if (ld == H) {
+        QSAE_HIP(hipMemsetAsync(dense, 0, static_cast<size_t>(B) * H * sizeof(float), s));
+    } else {
+        QSAE_HIP(hipMemset2DAsync(dense, static_cast<size_t>(ld) * sizeof(float), 0,
+                                  static_cast<size_t>(H) * sizeof(float), B, s));
+    }
+    const long long total = static_cast<long long>(B) * k;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, idx,
+                       val, total, k, H, dense, ld);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+extern "C" int qsae_sq_err_sum(const float* recon, const float* x, size_t n, double* sum, qsae_stream_t stream) {
+    if (n == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(recon && x && sum, "null pointer");
+    QSAE_CHECK_ARG(aligned16(recon) && aligned16(x), "recon and x must be 16-byte aligned");
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(sq_err_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), recon, x,
+                       n, sum);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}

@@ -1,0 +1,239 @@
+"""Tensor-level front-end of the C ABI (include/qsae.h): torch supplies device memory and the
+current HIP stream, libqsae_hip.so does the work.  Every function requires CUDA (ROCm)
+tensors and raises otherwise -- there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, check  # noqa: F401
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: quantizedsae_amd runs on MI355X only; tensor is on {t.device} "
+                           "(no CPU fallback exists)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    _dev(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ---- encoder ------------------------------------------------------------------------------
+def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    if W.shape[1] != D:
+        raise ValueError(f"W is {tuple(W.shape)}, expected [H, {D}]")
+    b = _f32c(bias, "bias") if bias is not None else None
+    if out is None:
+        out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    check(_lib.load().qsae_encode_dense(_p(x), _p(W), _p(b), B, D, H, act, _p(out), out.stride(0) if B else H,
+                                        _stream()))
+    return out
+
+
+def encode_bits(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """uint32-packed z bits [B, ceil(H/32)] (returned as int32 tensor)."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    words = (H + 31) // 32
+    z = torch.empty((B, words), dtype=torch.int32, device=x.device)
+    check(_lib.load().qsae_encode_bits(_p(x), _p(W), _p(b), B, D, H, _p(z), words, _stream()))
+    return z
+
+
+def topk_rows(latent: torch.Tensor, k: int, zero_rest: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """In-place on `latent` when zero_rest.  Returns (idx int32 [B,k], val f32 [B,k])."""
+    _dev(latent, "latent", torch.float32)
+    if latent.dim() != 2 or latent.stride(1) != 1:
+        raise ValueError("latent must be a 2-D tensor with unit inner stride")
+    B, H = latent.shape
+    idx = torch.empty((B, k), dtype=torch.int32, device=latent.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=latent.device)
+    check(_lib.load().qsae_topk_rows(_p(latent), latent.stride(0) if B else H, B, H, k, _p(idx), _p(val),
+                                     1 if zero_rest else 0, _stream()))
+    return idx, val
+
+
+_workspaces = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], k: int):
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    lib = _lib.load()
+    need = int(lib.qsae_encode_topk_workspace_bytes(B, D, H, k))
+    ws = _workspace(x.device, need)
+    idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=x.device)
+    check(lib.qsae_encode_topk(_p(x), _p(W), _p(b), B, D, H, k, _p(idx), _p(val), _p(ws), ws.numel(), _stream()))
+    return idx, val
+
+
+def densify(idx: torch.Tensor, val: torch.Tensor, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(idx, "idx", torch.int32)
+    _dev(val, "val", torch.float32)
+    B, k = idx.shape
+    if out is None:
+        out = torch.empty((B, H), dtype=torch.float32, device=idx.device)
+    check(_lib.load().qsae_densify(_p(idx.contiguous()), _p(val.contiguous()), B, k, H, _p(out),
+                                   out.stride(0) if B else H, _stream()))
+    return out
+
+
+# ---- BinarySAE dictionary -----------------------------------------------------------------
+def binary_row_bytes(D: int, n_bits: int) -> int:
+    r = int(_lib.load().qsae_binary_row_bytes(D, n_bits))
+    if r < 0:
+        check(r)
+    return r
+
+
+def pack_binary(logits: torch.Tensor, D: int, n_bits: int, want_polarize: bool = True):
+    """-> (packed uint8 [H, row_bytes], polarize_sum float64 0-d tensor or None)."""
+    logits = _f32c(logits, "logits")
+    H = logits.shape[0]
+    if logits.shape[1] != D * n_bits:
+        raise ValueError(f"logits is {tuple(logits.shape)}, expected [H, {D * n_bits}]")
+    packed = torch.empty((H, binary_row_bytes(D, n_bits)), dtype=torch.uint8, device=logits.device)
+    pol = torch.zeros((), dtype=torch.float64, device=logits.device) if want_polarize else None
+    check(_lib.load().qsae_pack_binary(_p(logits), H, D, n_bits, _p(packed), _p(pol), _stream()))
+    return packed, pol
+
+
+def unpack_binary(packed: torch.Tensor, D: int, n_bits: int) -> torch.Tensor:
+    _dev(packed, "packed", torch.uint8)
+    H = packed.shape[0]
+    out = torch.empty((H, D), dtype=torch.float32, device=packed.device)
+    check(_lib.load().qsae_unpack_binary(_p(packed), H, D, n_bits, _p(out), _stream()))
+    return out
+
+
+def binary_soft_table(logits: torch.Tensor, D: int, n_bits: int) -> torch.Tensor:
+    logits = _f32c(logits, "logits")
+    H = logits.shape[0]
+    out = torch.empty((H, D), dtype=torch.float32, device=logits.device)
+    check(_lib.load().qsae_binary_soft_table(_p(logits), H, D, n_bits, _p(out), _stream()))
+    return out
+
+
+def decode_binary_sparse(idx, val, packed, D: int, n_bits: int, step: float, bias=None) -> torch.Tensor:
+    _dev(idx, "idx", torch.int32)
+    _dev(val, "val", torch.float32)
+    _dev(packed, "packed", torch.uint8)
+    B, k = idx.shape
+    H = packed.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    recon = torch.empty((B, D), dtype=torch.float32, device=idx.device)
+    check(_lib.load().qsae_decode_binary_sparse(_p(idx.contiguous()), _p(val.contiguous()), B, k, _p(packed), H, D,
+                                                n_bits, float(step), _p(b), _p(recon), _stream()))
+    return recon
+
+
+def decode_table_sparse(idx, val, table: torch.Tensor, scale: float = 1.0, bias=None) -> torch.Tensor:
+    _dev(idx, "idx", torch.int32)
+    _dev(val, "val", torch.float32)
+    table = _f32c(table, "table")
+    B, k = idx.shape
+    H, D = table.shape
+    b = _f32c(bias, "bias") if bias is not None else None
+    recon = torch.empty((B, D), dtype=torch.float32, device=idx.device)
+    check(_lib.load().qsae_decode_table_sparse(_p(idx.contiguous()), _p(val.contiguous()), B, k, _p(table), H, D,
+                                               float(scale), _p(b), _p(recon), _stream()))
+    return recon
+
+
+# ---- ternary ---------------------------------------------------------------------------------
+def pack_ternary(w: torch.Tensor) -> torch.Tensor:
+    """decoder.weight [D, H] -> 2-bit codes int32 [D, ceil(H/16)]."""
+    w = _f32c(w, "w")
+    D, H = w.shape
+    codes = torch.empty((D, (H + 15) // 16), dtype=torch.int32, device=w.device)
+    check(_lib.load().qsae_pack_ternary(_p(w), D, H, _p(codes), _stream()))
+    return codes
+
+
+def decode_ternary_dense(h: torch.Tensor, codes: torch.Tensor, D: int) -> torch.Tensor:
+    _dev(h, "h", torch.float32)
+    B, H = h.shape
+    recon = torch.empty((B, D), dtype=torch.float32, device=h.device)
+    check(_lib.load().qsae_decode_ternary_dense(_p(h), h.stride(0) if B else H, B, H, _p(codes), D, _p(recon),
+                                                _stream()))
+    return recon
+
+
+# ---- matryoshka ------------------------------------------------------------------------------
+def matryoshka_sizes(H: int, n_bits: int):
+    arr = (C.c_int32 * n_bits)()
+    check(_lib.load().qsae_matryoshka_sizes(H, n_bits, C.cast(arr, C.c_void_p)))
+    return [int(v) for v in arr]
+
+
+def pack_matryoshka(w: torch.Tensor, wm: torch.Tensor, n_bits: int, abs_range: float):
+    w, wm = _f32c(w, "w"), _f32c(wm, "wm")
+    H, D = w.shape
+    codes = torch.empty((D, (H + 15) // 16), dtype=torch.int32, device=w.device)
+    scale = torch.empty((H,), dtype=torch.float32, device=w.device)
+    check(_lib.load().qsae_pack_matryoshka(_p(w), _p(wm), H, D, n_bits, float(abs_range), _p(codes), _p(scale),
+                                           _stream()))
+    return codes, scale
+
+
+def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, scale, bias, allow_bias: bool):
+    """-> (levels f32 [n_bits, B, D], l0_counts int64 [n_bits])."""
+    _dev(zbits, "zbits", torch.int32)
+    B = zbits.shape[0]
+    levels = torch.empty((n_bits, B, D), dtype=torch.float32, device=zbits.device)
+    counts = torch.zeros((n_bits,), dtype=torch.int64, device=zbits.device)
+    b = _f32c(bias, "bias") if bias is not None else None
+    check(_lib.load().qsae_decode_matryoshka(_p(zbits), zbits.stride(0) if B else (H + 31) // 32, B, H, D, n_bits,
+                                             _p(codes), _p(scale), _p(b), 1 if allow_bias else 0, _p(levels),
+                                             _p(counts), _stream()))
+    return levels, counts
+
+
+# ---- metric ------------------------------------------------------------------------------------
+def sq_err_sum(recon: torch.Tensor, x: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """acc (float64 0-d device tensor) += sum((recon - x)^2); returns acc (no host sync)."""
+    recon, x = _f32c(recon, "recon"), _f32c(x, "x")
+    if recon.shape != x.shape:
+        raise ValueError("recon and x must have the same shape")
+    if acc is None:
+        acc = torch.zeros((), dtype=torch.float64, device=x.device)
+    check(_lib.load().qsae_sq_err_sum(_p(recon), _p(x), recon.numel(), _p(acc), _stream()))
+    return acc

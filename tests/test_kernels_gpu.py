@@ -1,0 +1,297 @@
+"""Parity of every HIP kernel (through the C ABI, via quantizedsae_amd.ops) against the CPU
+oracle on the same seeded inputs.  Bit-exact for the encoder chain, top-k indices, packers and
+the sparse decode; 1e-5 relative for the dense decoders (tolerance of north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_util import rel_err
+from quantizedsae_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from quantizedsae_amd import ops
+    return ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def set_gemm_config(cfg):
+    from quantizedsae_amd import _lib
+    lib = _lib.load()
+    lib.qsae_debug_set_gemm_config.argtypes = [C.c_int]
+    lib.qsae_debug_set_gemm_config(cfg)
+
+
+@pytest.fixture(autouse=True)
+def _reset_cfg():
+    yield
+    set_gemm_config(0)
+
+
+# ---- encoder ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("B,D,H", [(300, 64, 1000), (256, 512, 2048), (257, 48, 520), (1, 512, 33), (513, 32, 257)])
+def test_encode_dense_bitexact(cfg, B, D, H):
+    ops = _ops()
+    set_gemm_config(cfg)
+    x = S.activations(7, B, D)
+    W = S.xavier_uniform(7, H, D, stream=1)
+    bias = S.normal(7, (H,), stream=3, std=0.1)
+    want = oracle.encode(x, W, bias, oracle.ACT_NONE)
+    got = host(ops.encode_dense(dev(x), dev(W), dev(bias), ops.ACT_NONE))
+    assert np.array_equal(got, want), f"max abs diff {np.abs(got - want).max()}"
+    want_relu = np.maximum(want, 0)
+    assert np.array_equal(host(ops.encode_dense(dev(x), dev(W), dev(bias), ops.ACT_RELU)), want_relu)
+    got_nb = host(ops.encode_dense(dev(x), dev(W), None, ops.ACT_NONE))
+    assert np.array_equal(got_nb, oracle.encode(x, W, None, oracle.ACT_NONE))
+    sig = host(ops.encode_dense(dev(x), dev(W), dev(bias), ops.ACT_SIGMOID))
+    np.testing.assert_allclose(sig, 1.0 / (1.0 + np.exp(-want.astype(np.float64))), rtol=2e-6, atol=1e-7)
+
+
+def test_encode_dense_strided_out_and_empty():
+    ops = _ops()
+    x = S.activations(8, 70, 64)
+    W = S.xavier_uniform(8, 96, 64, stream=1)
+    big = torch.full((70, 128), -7.0, device=DEV)
+    ops.encode_dense(dev(x), dev(W), None, ops.ACT_NONE, out=big[:, :96])
+    assert np.array_equal(host(big[:, :96]), oracle.encode(x, W, None))
+    assert (big[:, 96:] == -7.0).all()
+    empty = ops.encode_dense(torch.empty((0, 64), device=DEV), dev(W), None)
+    assert tuple(empty.shape) == (0, 96)
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("B,D,H", [(300, 64, 1000), (130, 512, 4096), (5, 48, 70)])
+def test_encode_bits_bitexact(cfg, B, D, H):
+    ops = _ops()
+    set_gemm_config(cfg)
+    x = S.activations(9, B, D)
+    W = S.xavier_uniform(9, H, D, stream=1)
+    bias = S.normal(9, (H,), stream=3, std=0.05)
+    pre = oracle.encode(x, W, bias)
+    want = oracle.zbits(pre)
+    z = host(ops.encode_bits(dev(x), dev(W), dev(bias))).view(np.uint32)
+    got = np.unpackbits(z.view(np.uint8), axis=1, bitorder="little")[:, :H]
+    assert np.array_equal(got, want)
+    # padding bits beyond H are zero
+    assert np.unpackbits(z.view(np.uint8), axis=1, bitorder="little")[:, H:].sum() == 0
+
+
+def test_encode_bits_cutoff_edge():
+    """pre-activations sitting exactly on the fp32 sigmoid cutoff (x=1 on one input, W = value)."""
+    ops = _ops()
+    gt, _ = oracle.sigmoid_cutoffs()
+    vals = np.array([gt, np.nextafter(gt, np.float32(-1)), 0.0, -0.0, 1e-7, 5e-8, -1e-9, 1.0], np.float32)
+    H, D = 32, 4
+    W = np.zeros((H, D), np.float32)
+    W[: len(vals), 0] = vals
+    x = np.zeros((3, D), np.float32)
+    x[:, 0] = 1.0
+    z = host(ops.encode_bits(dev(x), dev(W), None)).view(np.uint32)
+    want = oracle.zbits(oracle.encode(x, W, None))
+    got = np.unpackbits(z.view(np.uint8), axis=1, bitorder="little")[:, :H]
+    assert np.array_equal(got, want)
+    assert got[0, :8].tolist() == [1, 0, 0, 0, 1, 0, 0, 1]
+
+
+# ---- top-k -------------------------------------------------------------------------------------
+def _check_topk(lat, k):
+    ops = _ops()
+    want_idx, want_val = oracle.topk(lat, k)
+    t = dev(lat)
+    idx, val = ops.topk_rows(t, k, zero_rest=True)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    dense = host(t)
+    want_dense = oracle.densify(want_idx, want_val, lat.shape[1])
+    # NaN-safe comparison of the masked latent
+    assert np.array_equal(np.nan_to_num(dense, nan=12345.0), np.nan_to_num(want_dense, nan=12345.0))
+    t2 = dev(lat)
+    idx2, _ = ops.topk_rows(t2, k, zero_rest=False)
+    assert np.array_equal(host(idx2), want_idx)
+    assert np.array_equal(host(t2).view(np.uint32), lat.view(np.uint32))
+
+
+@pytest.mark.parametrize("H,k", [(32768, 65), (32768, 32), (32768, 1), (32768, 256), (1000, 2), (1000, 250),
+                                 (2048, 65), (4, 3), (8192, 16), (16384, 65)])
+def test_topk_random(H, k):
+    lat = S.normal(3, (37, H), stream=H % 97)
+    _check_topk(lat, k)
+
+
+def test_topk_ties_and_specials():
+    H = 32768
+    rows = []
+    rows.append(np.zeros(H, np.float32))                                   # all equal -> radix fallback
+    rows.append(np.full(H, -3.5, np.float32))
+    r = np.zeros(H, np.float32); r[::7] = 1.0; rows.append(r)               # massive ties at the boundary
+    r = S.normal(5, (H,), stream=1); r[[5, 77, 30000]] = np.nan; rows.append(r)
+    r = S.normal(5, (H,), stream=2); r[[1, 2]] = np.inf; r[[9, 10]] = -np.inf; rows.append(r)
+    r = np.arange(H, dtype=np.float32); rows.append(r)                     # ascending
+    rows.append(r[::-1].copy())                                            # descending
+    r = S.normal(5, (H,), stream=3) * 1e-3                                  # large values owned by 10 threads only
+    e = np.arange(H); own = ((e // 4) % 256) < 10
+    r[own] = 5.0 + S.normal(5, (int(own.sum()),), stream=4); rows.append(r)
+    r = np.round(S.normal(5, (H,), stream=6) * 2).astype(np.float32); rows.append(r)   # few distinct values
+    r = np.where(np.arange(H) % 2 == 0, 0.0, -0.0).astype(np.float32); rows.append(r)  # +-0 ties
+    lat = np.stack(rows)
+    for k in (65, 1, 256):
+        _check_topk(lat, k)
+
+
+def test_topk_strided_rows():
+    ops = _ops()
+    lat = S.normal(6, (9, 1024), stream=1)
+    buf = torch.zeros((9, 2048), device=DEV)
+    buf[:, :1024] = dev(lat)
+    idx, val = ops.topk_rows(buf[:, :1024], 5, zero_rest=True)
+    want_idx, want_val = oracle.topk(lat, 5)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(buf[:, :1024]), oracle.densify(want_idx, want_val, 1024))
+
+
+@pytest.mark.parametrize("B,D,H,k", [(70, 64, 1000, 2), (1500, 512, 2048, 65)])
+def test_encode_topk_equals_two_step(B, D, H, k):
+    ops = _ops()
+    x = S.activations(10, B, D)
+    W = S.xavier_uniform(10, H, D, stream=1)
+    bias = S.normal(10, (H,), stream=3, std=0.05)
+    idx, val = ops.encode_topk(dev(x), dev(W), dev(bias), k)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val), want_val)
+
+
+# ---- BinarySAE dictionary ---------------------------------------------------------------------
+@pytest.mark.parametrize("n_bits", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("D,H", [(512, 600), (48, 100), (20, 64)])
+def test_pack_and_sparse_decode_binary(n_bits, D, H):
+    ops = _ops()
+    logits = S.normal(20 + n_bits, (H, D * n_bits), stream=1, std=3.0)
+    gt, _ = oracle.sigmoid_cutoffs()
+    logits[0, :8] = [0.0, -0.0, gt, np.nextafter(gt, np.float32(-1)), 1e-7, -1e-7, 5e-8, 30.0][: 8]
+    packed, pol = ops.pack_binary(dev(logits), D, n_bits)
+    want_packed = oracle.pack_binary(logits, D, n_bits)
+    assert np.array_equal(host(packed), want_packed)
+    total = H * D * n_bits
+    assert float(pol.item()) / total == pytest.approx(oracle.polarize(logits, D, n_bits), rel=1e-5)
+    assert np.array_equal(host(ops.unpack_binary(packed, D, n_bits)), oracle.unpack_binary(want_packed, D, n_bits))
+    # sparse decode, several k including ragged tails of the unrolled loop
+    for k in (1, 3, 4, 65):
+        kk = min(k, H)
+        B = 19
+        lat = S.normal(30, (B, H), stream=k)
+        idx, val = oracle.topk(lat, kk)
+        bias = S.normal(31, (D,), stream=2, std=0.3)
+        step = np.float32(4.0 / 2 ** (n_bits - 1))
+        got = host(ops.decode_binary_sparse(dev(idx), dev(val), packed, D, n_bits, float(step), dev(bias)))
+        want = oracle.decode_binary(idx, val, want_packed, D, n_bits, float(step), bias)
+        assert np.array_equal(got, want), (n_bits, D, H, k)
+    got = host(ops.decode_binary_sparse(dev(idx), dev(val), packed, D, n_bits, 0.1875, None))
+    assert np.array_equal(got, oracle.decode_binary(idx, val, want_packed, D, n_bits, 0.1875, None))
+
+
+def test_soft_table_and_table_decode():
+    ops = _ops()
+    H, D, n = 300, 64, 4
+    logits = S.normal(40, (H, D * n), stream=1, std=2.0)
+    table = host(ops.binary_soft_table(dev(logits), D, n))
+    p = 1.0 / (1.0 + np.exp(-logits.astype(np.float64)))
+    bw = np.array([1, 2, 4, -8], np.float64)
+    want = (p.reshape(H, D, n) * bw).sum(-1)
+    np.testing.assert_allclose(table, want, rtol=2e-6, atol=2e-6)
+    lat = S.normal(41, (23, H), stream=1)
+    idx, val = oracle.topk(lat, 32)
+    tab = S.normal(42, (H, D), stream=2)
+    bias = S.normal(42, (D,), stream=3)
+    for scale in (1.0, 0.5):
+        got = host(ops.decode_table_sparse(dev(idx), dev(val), dev(tab), scale, dev(bias)))
+        assert np.array_equal(got, oracle.decode_table(idx, val, tab, scale, bias))
+
+
+def test_densify_and_sq_err():
+    ops = _ops()
+    B, H, k = 33, 1000, 7
+    lat = S.normal(50, (B, H), stream=1)
+    idx, val = oracle.topk(lat, k)
+    got = host(ops.densify(dev(idx), dev(val), H))
+    assert np.array_equal(got, oracle.densify(idx, val, H))
+    a = S.normal(51, (B, 515), stream=1)
+    b = S.normal(51, (B, 515), stream=2)
+    s = float(ops.sq_err_sum(dev(a), dev(b)).item())
+    assert s == pytest.approx(oracle.sq_err_sum(a, b), rel=1e-12)
+
+
+# ---- dense decoders ------------------------------------------------------------------------------
+def _unpack2(words, n):
+    w = words.view(np.uint32)
+    f = (w[:, :, None] >> (2 * np.arange(16, dtype=np.uint32))[None, None, :]) & 3
+    f = f.reshape(w.shape[0], -1)[:, :n].astype(np.int8)
+    return np.where(f == 3, -1, f).astype(np.int8)
+
+
+@pytest.mark.parametrize("B,D,H", [(100, 64, 1000), (300, 512, 4096), (7, 512, 32768)])
+def test_ternary_pack_and_decode(B, D, H):
+    ops = _ops()
+    w = S.normal(60, (D, H), stream=1, std=0.5)
+    w[0, :6] = [0.5, -0.5, 0.49999997, -0.49999997, 0.0, np.nan]
+    codes = ops.pack_ternary(dev(w))
+    want_codes = oracle.ternary_codes(w)
+    assert np.array_equal(_unpack2(host(codes), H), want_codes)
+    h = np.maximum(S.normal(61, (B, H), stream=2), 0).astype(np.float32)
+    got = host(ops.decode_ternary_dense(dev(h), codes, D))
+    want = oracle.decode_ternary(h, want_codes)
+    assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("B,D,H,n_bits,abs_range", [(100, 64, 1024, 4, 4.0), (300, 512, 4096, 4, 1.5),
+                                                     (9, 512, 32768, 4, 4.0), (50, 64, 512, 1, 1.5)])
+def test_matryoshka_pack_and_decode(B, D, H, n_bits, abs_range):
+    ops = _ops()
+    sd = S.matryoshka_sae_params(70, D, H, bias_std=0.3)
+    w, wm, bias = sd["decoder.weight"], sd["decoder.weight_mirror"], sd["decoder.bias"]
+    _, ge = oracle.sigmoid_cutoffs()
+    w[0, :4] = [ge, np.nextafter(ge, np.float32(-1)), 0.0, -1e-7]
+    codes, scale = ops.pack_matryoshka(dev(w), dev(wm), n_bits, abs_range)
+    want_codes, want_scale = oracle.matryoshka_pack(w, wm, n_bits, abs_range)
+    assert ops.matryoshka_sizes(H, n_bits) == oracle.matryoshka_sizes(H, n_bits)
+    assert np.array_equal(_unpack2(host(codes), H).T * 2, want_codes)
+    assert np.array_equal(host(scale), want_scale)
+    zb = (S.uniform(71, (B, H), 0, 1, stream=3) < 0.01).astype(np.uint8)
+    zwords = np.packbits(zb, axis=1, bitorder="little").view(np.int32)
+    levels, counts = ops.decode_matryoshka(dev(zwords), H, D, n_bits, codes, scale, dev(bias), True)
+    want_levels, want_l0 = oracle.decode_matryoshka(zb, want_codes, want_scale, bias, n_bits, True)
+    for i in range(n_bits):
+        assert rel_err(host(levels[i]), want_levels[i]) < 1e-5, i
+    np.testing.assert_allclose(host(counts) / B, want_l0, rtol=1e-6)
+    levels_nb, _ = ops.decode_matryoshka(dev(zwords), H, D, n_bits, codes, scale, dev(bias), False)
+    want_nb, _ = oracle.decode_matryoshka(zb, want_codes, want_scale, bias, n_bits, False)
+    assert rel_err(host(levels_nb[-1]), want_nb[-1]) < 1e-5
+
+
+def test_error_codes():
+    from quantizedsae_amd import _lib
+    ops = _ops()
+    x = torch.zeros((4, 6), device=DEV)
+    W = torch.zeros((8, 6), device=DEV)
+    with pytest.raises(_lib.QsaeError) as e:
+        ops.encode_dense(x, W, None)           # D % 4 != 0
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.QsaeError):
+        ops.topk_rows(torch.zeros((2, 64), device=DEV), 65, True)   # k > H
+    with pytest.raises(RuntimeError):
+        ops.encode_dense(torch.zeros((4, 8)), torch.zeros((8, 8)), None)   # CPU tensors: no fallback
