@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: activations/sec (+ recon-MSE) of BinarySAE 512->32768 n_bits=4 forward.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one full ``BinarySAE.forward`` (reference signature: dense sparse latent [B, H],
+reconstruction [B, D], polarize loss) over one 65536-row batch of synthetic 512-d activations
+already resident in HBM, plus the on-device squared-error accumulation of the recon-MSE metric.
+Rows shard across ranks with no data-path collective (weak scaling: 65536 rows per GPU); the only
+exchange is the final 2-element fp64 all-reduce of the MSE pair and the max-over-ranks timing.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+D, H, N_BITS, GAMMA = 512, 32768, 4, 4.0
+ROWS_PER_GPU = 65536
+K_TOP = int(H * 0.002)
+FLOPS_PER_ROW_ENCODER = 2 * D * H                       # the dominant kernel
+FLOPS_PER_ROW = 2 * D * H + 2 * K_TOP * D               # 33 620 992 algorithmic FLOP per row
+BYTES_PER_ROW_DENSE = 4 * D + 4 * H + 4 * D             # 135 168 B per row, dense-latent return
+PEAK_FP32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, chip-level parameters
+
+
+def build_model(device, seed=1):
+    """BinarySAE(512, 32768, gamma=4, n_bits=4): xavier-uniform encoder, zero biases, saturated
+    +-30 decoder logits with fair random bits, torch generator on device."""
+    from quantizedsae_amd import BinarySAE
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    model = BinarySAE(D, H, gamma=GAMMA, n_bits=N_BITS).to(device).eval()
+    bound = (6.0 / (D + H)) ** 0.5
+    with torch.no_grad():
+        model.encoder[0].weight.copy_((torch.rand((H, D), device=device, generator=g) * 2 - 1) * bound)
+        model.encoder[0].bias.zero_()
+        bits = torch.randint(0, 2, (H, D * N_BITS), device=device, generator=g, dtype=torch.int8)
+        model.decoder.weight.copy_((bits.float() * 2 - 1) * 30.0)
+        model.decoder.bias.zero_()
+    return model
+
+
+def cpu_baseline(model, x_sample, threads):
+    """Time the torch-CPU restatement of the reference's op sequence (oracle/torch_restatement.py)
+    on the host cores, same weights, a bounded sample of the same batch."""
+    from oracle import torch_restatement as T
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    xs = x_sample.cpu()
+    args = (xs, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"], sd["decoder.bias"])
+    kw = dict(n_bits=N_BITS, gamma=GAMMA, k=K_TOP)
+    T.binary_forward(*args, **kw)      # warm-up
+    best = float("inf")
+    reps = 0
+    t_all = time.perf_counter()
+    while reps < 5 and (time.perf_counter() - t_all) < 25.0:
+        t0 = time.perf_counter()
+        T.binary_forward(*args, **kw)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    cpu_name = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": xs.shape[0] / best, "unit": "activations/s", "cores": threads, "kind": "port",
+            "sample": f"{xs.shape[0]} rows of the same batch and weights, torch-CPU op-sequence restatement of "
+                      f"BinarySAE.forward (oracle/torch_restatement.py), fp32, best of {reps}, host CPU: {cpu_name}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=4096)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from quantizedsae_amd import ops, sharding
+    model = build_model(device)
+    B = args.rows
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + rank)                       # every rank owns a different row shard
+    x = torch.randn((B, D), device=device, generator=g)
+    model.decoder.packed()                           # pack once, outside the timed region
+    sq = torch.zeros((), dtype=torch.float64, device=device)
+
+    def step(acc):
+        latent, recon, _pol = model(x)
+        ops.sq_err_sum(recon, x, acc)
+        return latent, recon
+
+    for _ in range(args.warmup):
+        step(torch.zeros((), dtype=torch.float64, device=device))
+    ops.kernel_timer.reset()
+    ops.kernel_timer.enabled = True
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(sq)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.kernel_timer.enabled = False
+    elapsed = sharding.max_over_ranks(elapsed, device=device)
+    mse = sharding.reduce_mse(sq, args.steps * B * D)
+
+    if rank == 0:
+        total_rows = world * B * args.steps
+        value = total_rows / elapsed
+        enc_ms = ops.kernel_timer.mean_ms("encode_dense")
+        achieved = FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12 if enc_ms else None
+        out = {
+            "metric": "activations/sec, BinarySAE 512->32768 n_bits=4 forward (dense latent + reconstruction + MSE)",
+            "value": value,
+            "unit": "activations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BinarySAE(512, 32768, gamma=4.0, n_bits=4) k=65, {B} rows per GPU per step, "
+                                   "reference forward() signature (dense [B,32768] latent, [B,512] reconstruction, "
+                                   "polarize loss) + recon-MSE accumulation",
+                       "rows_per_gpu": B, "input_dim": D, "hidden_dim": H, "n_bits": N_BITS, "gamma": GAMMA,
+                       "top_k": K_TOP, "parallelism": f"row-sharded x{world}, no data-path collective"},
+            "recon_mse": mse,
+            "whole_path_tflops_per_gpu": value / world * FLOPS_PER_ROW / 1e12,
+            "whole_path_dense_gbps_per_gpu": value / world * BYTES_PER_ROW_DENSE / 1e9,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (encoder 65536x512 @ 512x32768, fp32 MFMA)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
+                         "avg_kernel_ms": enc_ms, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                pass
+            out["cpu_baseline"] = cpu_baseline(model, x[: args.cpu_sample_rows], threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -129,16 +129,24 @@ int qsae_decode_ternary_dense(const float* h, int64_t ld, int B, int H, const ui
 int qsae_matryoshka_sizes(int H, int n_bits, int32_t* sizes);
 /* codes2t [D][ceil(H/16)] uint32 2-bit two's-complement fields of S/2 in {-1,0,+1} where
  * S = sgn(sig(w)>=.5)+sgn(sig(wm)>=.5) (:67-80), transposed so that H is contiguous;
- * scale[j] = reciprocal(||S_j||+1e-8) * 2^(n-i-2) * abs_range/2^(n-1) for j in level i (:82-90). */
+ * scale[j] = reciprocal(||S_j||+1e-8) * 2^(n-i-2) * abs_range/2^(n-1) for j in level i (:82-90).
+ * level_sizes: HOST array of n_bits level sizes summing to H, or NULL for qsae_matryoshka_sizes(H)
+ * (a caller that pads levels to multiples of 32 passes the padded sizes). */
 int qsae_pack_matryoshka(const float* w, const float* wm, int H, int D, int n_bits, float abs_range,
-                         uint32_t* codes2t, float* scale, qsae_stream_t stream);
+                         const int32_t* level_sizes, uint32_t* codes2t, float* scale,
+                         qsae_stream_t stream);
 /* levels[i][b][d] cumulative reconstructions (:121-129), l0_counts[i] = number of set z bits in
  * level i over the whole batch (latent_group[i] = l0_counts[i] / B, :128).
- * zbits as produced by qsae_encode_bits. */
+ * zbits as produced by qsae_encode_bits.  Level boundaries (and H) must be multiples of 32. */
 int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
-                           const uint32_t* codes2t, const float* scale, const float* bias,
-                           int allow_bias, float* levels, unsigned long long* l0_counts,
-                           qsae_stream_t stream);
+                           const int32_t* level_sizes, const uint32_t* codes2t, const float* scale,
+                           const float* bias, int allow_bias, float* levels,
+                           unsigned long long* l0_counts, qsae_stream_t stream);
+/* zbits[b][w] bit j = dense[b][32w+j] > thr -- the `latent > 0.5` binarisation applied to an
+ * already materialised sigmoid latent (sae/quantized_matryoshka.py:97-99 when the decoder is
+ * called directly, scripts/analysis/dynamic_analysis.py:51,66). */
+int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, float thr, uint32_t* zbits,
+                      int64_t words_ld, qsae_stream_t stream);
 
 /* -- metric ------------------------------------------------------------------------------ */
 /* *sum += sum_i (float)((recon[i]-x[i])^2) accumulated in double (device pointer; the caller

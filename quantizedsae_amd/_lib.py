@@ -38,8 +38,9 @@ SIGNATURES = {
     "qsae_pack_ternary": (_i, [_vp, _i, _i, _vp, _vp]),
     "qsae_decode_ternary_dense": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
     "qsae_matryoshka_sizes": (_i, [_i, _i, _vp]),
-    "qsae_pack_matryoshka": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
-    "qsae_decode_matryoshka": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "qsae_pack_matryoshka": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "qsae_decode_matryoshka": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "qsae_pack_bits_gt": (_i, [_vp, _i64, _i, _i, _f, _vp, _i64, _vp]),
     "qsae_sq_err_sum": (_i, [_vp, _vp, _sz, _vp, _vp]),
 }
 

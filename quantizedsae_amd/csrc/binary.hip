@@ -55,7 +55,7 @@ unpack_binary_kernel(const uint32_t* __restrict__ packed, int H, int D, int n, i
     const int h = static_cast<int>(gid / D), d = static_cast<int>(gid % D);
     const int F = 32 / fw;
     const uint32_t word = packed[static_cast<long long>(h) * row_dwords + d / F];
-    out[gid] = static_cast<float>(__builtin_amdgcn_sbfe(static_cast<int>(word), (d % F) * fw, n));
+    out[gid] = static_cast<float>(sbfe_i32(static_cast<int>(word), (d % F) * fw, n));
 }
 
 // table[h][d] = sum_b sigmoid(logit[h][d*n+b]) * bw[b], bw = [1,2,..,-2^(n-1)]  (binary.py:26-35)
@@ -146,14 +146,14 @@ decode_binary_sparse_kernel(const int32_t* __restrict__ idx, const float* __rest
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int f = 0; f < F; ++f)
-                    acc[f] = fmaf(a[u], static_cast<float>(__builtin_amdgcn_sbfe(static_cast<int>(w[u]), f * FW, n)), acc[f]);
+                    acc[f] = fmaf(a[u], static_cast<float>(sbfe_i32(static_cast<int>(w[u]), f * FW, n)), acc[f]);
         }
         for (; j < k; ++j) {
             const uint32_t w = packed[static_cast<long long>(s_idx[j]) * row_dwords + c];
             const float a = s_val[j];
 #pragma unroll
             for (int f = 0; f < F; ++f)
-                acc[f] = fmaf(a, static_cast<float>(__builtin_amdgcn_sbfe(static_cast<int>(w), f * FW, n)), acc[f]);
+                acc[f] = fmaf(a, static_cast<float>(sbfe_i32(static_cast<int>(w), f * FW, n)), acc[f]);
         }
         float* out = recon + static_cast<long long>(b) * D + c * F;
 #pragma unroll

@@ -67,6 +67,13 @@ __device__ __forceinline__ uint32_t key_index(unsigned long long key) {
     return ~static_cast<uint32_t>(key & 0xFFFFFFFFull);
 }
 
+// Signed bit-field extract (v_bfe_i32): `width` bits at `offset`, sign-extended.  The clang
+// builtin is typed unsigned; the cast restores the signed result.
+__device__ __forceinline__ int sbfe_i32(int v, int offset, int width) {
+    return static_cast<int>(__builtin_amdgcn_sbfe(static_cast<unsigned>(v), static_cast<unsigned>(offset),
+                                                  static_cast<unsigned>(width)));
+}
+
 __host__ __device__ inline int field_width(int n_bits) {
     return n_bits <= 1 ? 1 : n_bits <= 2 ? 2 : n_bits <= 4 ? 4 : 8;
 }

@@ -184,10 +184,20 @@ count_bits_kernel(const uint32_t* __restrict__ zbits, int64_t words_ld, int B, i
     }
 }
 
-static int make_levels(int H, int n_bits, float abs_range, LevelTable& lv) {
+static int make_levels(int H, int n_bits, float abs_range, const int32_t* level_sizes, LevelTable& lv) {
     int32_t sizes[kMaxLevels];
-    const int rc = qsae_matryoshka_sizes(H, n_bits, sizes);
-    if (rc != QSAE_OK) return rc;
+    if (level_sizes) {
+        long long sum = 0;
+        for (int i = 0; i < n_bits; ++i) {
+            if (level_sizes[i] < 0) return fail(QSAE_ERR_INVALID_ARG, "%s: negative level size", __func__);
+            sizes[i] = level_sizes[i];
+            sum += sizes[i];
+        }
+        if (sum != H) return fail(QSAE_ERR_INVALID_ARG, "%s: level sizes do not sum to H", __func__);
+    } else {
+        const int rc = qsae_matryoshka_sizes(H, n_bits, sizes);
+        if (rc != QSAE_OK) return rc;
+    }
     lv.n = n_bits;
     int acc = 0;
     const double quant_step = static_cast<double>(abs_range) / static_cast<double>(1u << (n_bits - 1));
@@ -268,11 +278,12 @@ extern "C" int qsae_decode_ternary_dense(const float* h, int64_t ld, int B, int 
 }
 
 extern "C" int qsae_pack_matryoshka(const float* w, const float* wm, int H, int D, int n_bits, float abs_range,
-                                    uint32_t* codes2t, float* scale, qsae_stream_t stream) {
+                                    const int32_t* level_sizes, uint32_t* codes2t, float* scale,
+                                    qsae_stream_t stream) {
     QSAE_CHECK_ARG(H > 0 && D > 0 && w && wm && codes2t && scale, "H > 0, D > 0, non-null pointers");
     QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= kMaxLevels, "1 <= n_bits <= 8 required");
     LevelTable lv;
-    const int rc = make_levels(H, n_bits, abs_range, lv);
+    const int rc = make_levels(H, n_bits, abs_range, level_sizes, lv);
     if (rc != QSAE_OK) return rc;
     hipStream_t s = as_stream(stream);
     const int words = (H + 15) / 16;
@@ -297,7 +308,8 @@ static int run_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H,
 }
 
 extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
-                                      const uint32_t* codes2t, const float* scale, const float* bias,
+                                      const int32_t* level_sizes, const uint32_t* codes2t, const float* scale,
+                                      const float* bias,
                                       int allow_bias, float* levels, unsigned long long* l0_counts,
                                       qsae_stream_t stream) {
     QSAE_CHECK_ARG(B >= 0 && H > 0 && D > 0, "B >= 0, H > 0, D > 0 required");
@@ -307,7 +319,7 @@ extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, i
     QSAE_CHECK_ARG(words_ld >= (H + 31) / 32, "words_ld < ceil(H/32)");
     QSAE_CHECK_ARG(aligned16(scale), "scale must be 16-byte aligned");
     LevelTable lv;
-    const int rc = make_levels(H, n_bits, 1.0f, lv);
+    const int rc = make_levels(H, n_bits, 1.0f, level_sizes, lv);
     if (rc != QSAE_OK) return rc;
     QSAE_CHECK_SUPPORTED(H % 32 == 0, "H must be a multiple of 32 (pad the dictionary)");
     for (int i = 0; i < n_bits; ++i)

@@ -152,10 +152,10 @@ struct LoaderCode2 {
         for (int i = 0; i < PASSES; ++i) {
             const int w = static_cast<int>(r[i] >> sh);
             f32x4 v;
-            v[0] = static_cast<float>(MUL * __builtin_amdgcn_sbfe(w, 0, 2));
-            v[1] = static_cast<float>(MUL * __builtin_amdgcn_sbfe(w, 2, 2));
-            v[2] = static_cast<float>(MUL * __builtin_amdgcn_sbfe(w, 4, 2));
-            v[3] = static_cast<float>(MUL * __builtin_amdgcn_sbfe(w, 6, 2));
+            v[0] = static_cast<float>(MUL * sbfe_i32(w, 0, 2));
+            v[1] = static_cast<float>(MUL * sbfe_i32(w, 2, 2));
+            v[2] = static_cast<float>(MUL * sbfe_i32(w, 4, 2));
+            v[3] = static_cast<float>(MUL * sbfe_i32(w, 6, 2));
             lds_store_chunk(tile + (i * G::ROWS_PER_PASS + lrow) * G::LDS_STRIDE, c, v);
         }
     }

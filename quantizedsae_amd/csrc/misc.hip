@@ -48,9 +48,43 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
     if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(sum, acc);
 }
 
+// one wave per 64 words: lane l builds word (w0 + l) of a row from 32 consecutive floats
+__global__ void __launch_bounds__(256)
+pack_bits_gt_kernel(const float* __restrict__ dense, int64_t ld, int B, int H, float thr,
+                    uint32_t* __restrict__ zbits, int64_t words_ld, int words) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(B) * words) return;
+    const long long b = gid / words;
+    const int wi = static_cast<int>(gid % words);
+    const float* p = dense + b * ld + static_cast<long long>(wi) * 32;
+    uint32_t word = 0;
+    for (int j = 0; j < 32; ++j) {
+        const int h = wi * 32 + j;
+        if (h < H && p[j] > thr) word |= 1u << j;
+    }
+    zbits[b * words_ld + wi] = word;
+}
+
 }  // namespace qsae
 
 using namespace qsae;
+
+extern "C" int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, float thr, uint32_t* zbits,
+                                 int64_t words_ld, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0, "B >= 0 and H > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(dense && zbits, "null pointer");
+    const int words = (H + 31) / 32;
+    QSAE_CHECK_ARG(ld >= H && words_ld >= words, "leading dimension too small");
+    hipStream_t s = as_stream(stream);
+    if (words_ld > words)
+        QSAE_HIP(hipMemset2DAsync(zbits + words, words_ld * 4, 0, (words_ld - words) * 4, B, s));
+    const long long total = static_cast<long long>(B) * words;
+    hipLaunchKernelGGL(pack_bits_gt_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, dense,
+                       ld, B, H, thr, zbits, words_ld, words);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
 
 extern "C" int qsae_abi_version(void) { return QSAE_ABI_VERSION; }
 

@@ -1,0 +1,253 @@
+"""Registry, checkpoint loader and SAEWrapper (reference: inference/framework.py:39-359).
+
+Same names, argument meaning and error behaviour as the reference; the models behind the
+wrapper are the HIP-backed classes of ``quantizedsae_amd.sae``.  Differences, all deliberate:
+  * ``device=None`` resolves to the current ROCm device when one is present (the reference
+    defaults to CPU, where this backend cannot run);
+  * a ``t_sae`` entry exists next to the reference's four (north_star names it);
+  * checkpoints are read with ``torch.load(..., weights_only=True)``.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Callable, Dict, Iterable, Iterator, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..sae import (
+    BaselineSparseAutoencoder,
+    BinarySAE,
+    QuantizedMatryoshkaSAE,
+    ResidualQuantizedSAE,
+    TernarySparseAutoencoder,
+)
+
+try:  # optional dependency, as in the reference
+    from safetensors.torch import load_file as load_safetensors
+except ImportError:  # pragma: no cover
+    load_safetensors = None  # type: ignore[assignment]
+
+_MODULE_ROOT = Path(__file__).resolve().parent
+_TRAINED_ROOT = _MODULE_ROOT / "Trained_SAEs"
+
+DeviceLike = Union[torch.device, str]
+
+
+def _default_device(device: Optional[DeviceLike]) -> torch.device:
+    if device is not None:
+        return torch.device(device)
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _detach_to_cpu(tensor: torch.Tensor) -> torch.Tensor:
+    return tensor.detach().cpu().clone()
+
+
+def _ensure_tensor(batch: Any) -> torch.Tensor:
+    if isinstance(batch, (list, tuple)):
+        if not batch:
+            raise ValueError("Received an empty batch; cannot infer tensor input.")
+        batch = batch[0]
+    if not isinstance(batch, torch.Tensor):
+        raise TypeError(f"Expected batch to be a torch.Tensor, received {type(batch)} instead.")
+    return batch
+
+
+ForwardAdapter = Callable[[nn.Module, torch.Tensor], Dict[str, Any]]
+DecoderExtractor = Callable[[nn.Module, Dict[str, Any]], Dict[str, torch.Tensor]]
+
+
+@dataclass(frozen=True)
+class SAERegistryEntry:
+    name: str
+    constructor: Callable[..., nn.Module]
+    checkpoint_path: Path
+    checkpoint_format: str  # "torch" | "safetensors"
+    kwargs: Dict[str, Any]
+    forward_adapter: ForwardAdapter
+    decoder_getter: DecoderExtractor
+
+
+# -- forward adapters: variant outputs -> dicts (framework.py:76-111) ---------------------------
+def _forward_binary(model, batch):
+    latent, reconstruction, polarize_loss = model(batch)
+    return {"latent": latent, "reconstruction": reconstruction, "aux": {"polarize_loss": polarize_loss}}
+
+
+def _forward_levels(model, batch):
+    groups, levels = model(batch)
+    return {"latent_groups": groups, "reconstruction_levels": levels, "reconstruction": levels[-1]}
+
+
+def _forward_pair(model, batch):
+    latent, reconstruction = model(batch)
+    return {"latent": latent, "reconstruction": reconstruction}
+
+
+# -- decoder exports (framework.py:114-162) ------------------------------------------------------
+def _decoder_binary(model, options):
+    dec = model.decoder
+    with torch.no_grad():
+        weight = dec.quantization_step * dec.quantized_int_weights().to(torch.float32)
+    return {"weight": _detach_to_cpu(weight), "bias": _detach_to_cpu(dec.bias)}
+
+
+def _decoder_quantized(model, _):
+    dec = model.decoder
+    w, wm = _detach_to_cpu(dec.weight), _detach_to_cpu(dec.weight_mirror)
+    return {"weight": w, "weight_mirror": wm, "effective_weight": w + wm, "bias": _detach_to_cpu(dec.bias)}
+
+
+def _decoder_residual(model, _):
+    out: Dict[str, torch.Tensor] = {}
+    for level, sae in enumerate(model.saes):
+        w, wm = _detach_to_cpu(sae.decoder.weight), _detach_to_cpu(sae.decoder.weight_mirror)
+        out[f"level_{level}_weight"] = w
+        out[f"level_{level}_weight_mirror"] = wm
+        out[f"level_{level}_effective_weight"] = w + wm
+        if getattr(sae.decoder, "bias", None) is not None:
+            out[f"level_{level}_bias"] = _detach_to_cpu(sae.decoder.bias)
+    return out
+
+
+def _decoder_linear(model, _):
+    out = {"weight": _detach_to_cpu(model.decoder.weight)}
+    if getattr(model.decoder, "bias", None) is not None:
+        out["bias"] = _detach_to_cpu(model.decoder.bias)
+    return out
+
+
+def _entry(name, ctor, path, kwargs, fwd, dec, fmt="torch"):
+    return SAERegistryEntry(name=name, constructor=ctor, checkpoint_path=path, checkpoint_format=fmt,
+                            kwargs=kwargs, forward_adapter=fwd, decoder_getter=dec)
+
+
+SAE_REGISTRY: Dict[str, SAERegistryEntry] = {
+    "b_sae": _entry("b_sae", BinarySAE, _TRAINED_ROOT / "b_sae_32768_4_bits.pth",
+                    {"input_dim": 512, "hidden_dim": 32768, "gamma": 1.5, "n_bits": 4},
+                    _forward_binary, _decoder_binary),
+    "q_sae": _entry("q_sae", QuantizedMatryoshkaSAE, _TRAINED_ROOT / "q_sae_32768_4_bits.pth",
+                    {"input_dim": 512, "hidden_dim": 32768, "top_k": 32, "abs_range": 1.5, "n_bits": 4,
+                     "allow_bias": True},
+                    _forward_levels, _decoder_quantized),
+    "rq_sae": _entry("rq_sae", ResidualQuantizedSAE, _TRAINED_ROOT / "rq_sae_32768_4_bits.pth",
+                     {"input_dim": 512, "hidden_dim": 32768, "top_k": 32, "abs_range": 1.5, "n_bits": 4},
+                     _forward_levels, _decoder_residual),
+    "baseline_sae": _entry("baseline_sae", BaselineSparseAutoencoder, _MODULE_ROOT / "SAEs" / "baseline_sae_32768.pth",
+                           {"input_dim": 512, "hidden_dim": 32768}, _forward_pair, _decoder_linear),
+    # not in the reference registry (its ternary SAE is only reachable from training/trainer.py:34-35)
+    "t_sae": _entry("t_sae", TernarySparseAutoencoder, _TRAINED_ROOT / "t_sae_32768.pth",
+                    {"input_dim": 512, "hidden_dim": 32768}, _forward_pair, _decoder_linear),
+}
+
+
+# -- checkpoint loading (framework.py:227-277) ---------------------------------------------------
+def _remap_eleuther(raw: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    """EleutherAI sae.safetensors keys -> BaselineSparseAutoencoder keys; W_dec [H,D] -> decoder.weight [D,H]."""
+    return OrderedDict({
+        "encoder.0.weight": raw["encoder.weight"].clone(),
+        "encoder.0.bias": raw["encoder.bias"].clone(),
+        "decoder.weight": raw["W_dec"].clone().t().contiguous(),
+        "decoder.bias": raw["b_dec"].clone(),
+    })
+
+
+def _load_state_dict(entry: SAERegistryEntry) -> Dict[str, torch.Tensor]:
+    if not entry.checkpoint_path.exists():
+        raise FileNotFoundError(f"Checkpoint not found for '{entry.name}': {entry.checkpoint_path}")
+    if entry.checkpoint_format == "torch":
+        return torch.load(entry.checkpoint_path, map_location="cpu", weights_only=True)
+    if entry.checkpoint_format == "safetensors":
+        if load_safetensors is None:
+            raise ImportError("safetensors is required to load baseline SAE checkpoints; "
+                              "install it with `pip install safetensors`.")
+        state = load_safetensors(str(entry.checkpoint_path))
+        return state if "encoder.0.weight" in state else _remap_eleuther(state)
+    raise ValueError(f"Unsupported checkpoint format '{entry.checkpoint_format}' for SAE '{entry.name}'.")
+
+
+class SAEWrapper:
+    """Uniform inference interface over the SAE variants (framework.py:280-337).
+
+    >>> sae = load_sae("b_sae")
+    >>> out = sae(batch)                 # {"latent", "reconstruction", "aux": {...}}
+    >>> recon = sae.reconstruct(batch)
+    >>> dictionary = sae.decoder_dictionary()
+    """
+
+    def __init__(self, entry: SAERegistryEntry, model: nn.Module, device: Optional[DeviceLike]) -> None:
+        self._entry = entry
+        self.model = model
+        self.device = _default_device(device)
+        self.model.to(self.device)
+        self.model.eval()
+
+    def to(self, device: DeviceLike) -> "SAEWrapper":
+        self.device = torch.device(device)
+        self.model.to(self.device)
+        return self
+
+    def eval(self) -> "SAEWrapper":
+        self.model.eval()
+        return self
+
+    @torch.no_grad()
+    def __call__(self, batch: torch.Tensor) -> Dict[str, Any]:
+        batch = _ensure_tensor(batch).to(self.device)
+        return self._entry.forward_adapter(self.model, batch)
+
+    @torch.no_grad()
+    def reconstruct(self, batch: torch.Tensor) -> torch.Tensor:
+        return self(batch)["reconstruction"]
+
+    @torch.no_grad()
+    def reconstruct_loader(self, dataloader: Iterable[Any], *, return_details: bool = False,
+                           ) -> Iterator[Union[torch.Tensor, Dict[str, Any]]]:
+        for batch in dataloader:
+            outputs = self(batch)
+            yield outputs if return_details else outputs["reconstruction"]
+
+    def decoder_dictionary(self, **options: Any) -> Dict[str, torch.Tensor]:
+        return self._entry.decoder_getter(self.model, options)
+
+
+def available_saes() -> Dict[str, Path]:
+    """Model keys -> checkpoint paths."""
+    return {name: entry.checkpoint_path for name, entry in SAE_REGISTRY.items()}
+
+
+def load_sae(name: str, *, device: Optional[DeviceLike] = None, strict: bool = True) -> SAEWrapper:
+    """Instantiate an SAE variant, restore its weights and wrap it for inference."""
+    if name not in SAE_REGISTRY:
+        raise KeyError(f"Unknown SAE '{name}'. Available: {list(SAE_REGISTRY)}")
+    entry = SAE_REGISTRY[name]
+    state_dict = _load_state_dict(entry)
+    model = entry.constructor(**entry.kwargs)
+    model.load_state_dict(state_dict, strict=strict)
+    return SAEWrapper(entry, model, device)
+
+
+def compute_reconstruction_error(sae: SAEWrapper, loader: Iterable[Any], device: Optional[DeviceLike] = None) -> float:
+    """Reconstruction MSE over a loader: sum((recon - x)^2) / element count
+    (scripts/analysis/dynamic_analysis.py:76-100).  The squared error is reduced on the device in
+    fp64 and read back once at the end instead of one ``.item()`` per batch."""
+    if device is not None:
+        sae.to(device)
+    sae.eval()
+    acc = None
+    count = 0
+    with torch.no_grad():
+        for batch in loader:
+            batch = _ensure_tensor(batch).to(sae.device)
+            recon = sae.reconstruct(batch)
+            acc = ops.sq_err_sum(recon, batch, acc)
+            count += recon.numel()
+    if acc is None:
+        raise ValueError("empty loader")
+    return float(acc.item()) / count

@@ -17,6 +17,33 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _KernelTimer:
+    """Optional HIP-event bracket around selected launches (used by bench.py to time the dominant
+    kernel live inside the timed region).  Events are recorded on the stream the kernel is launched
+    on (torch's current stream) and read only after the region has been synchronised."""
+
+    def __init__(self):
+        self.enabled = False
+        self._events = {}
+
+    def reset(self):
+        self._events = {}
+
+    def bracket(self, name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self._events.setdefault(name, []).append((a, b))
+        return a, b
+
+    def mean_ms(self, name):
+        ev = self._events.get(name)
+        if not ev:
+            return None
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+kernel_timer = _KernelTimer()
+
+
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
@@ -50,8 +77,13 @@ def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     b = _f32c(bias, "bias") if bias is not None else None
     if out is None:
         out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    ev = kernel_timer.bracket("encode_dense") if kernel_timer.enabled else None
+    if ev:
+        ev[0].record()
     check(_lib.load().qsae_encode_dense(_p(x), _p(W), _p(b), B, D, H, act, _p(out), out.stride(0) if B else H,
                                         _stream()))
+    if ev:
+        ev[1].record()
     return out
 
 
@@ -204,27 +236,53 @@ def matryoshka_sizes(H: int, n_bits: int):
     return [int(v) for v in arr]
 
 
-def pack_matryoshka(w: torch.Tensor, wm: torch.Tensor, n_bits: int, abs_range: float):
+def _sizes_arg(sizes, n_bits):
+    if sizes is None:
+        return None, C.c_void_p(0)
+    if len(sizes) != n_bits:
+        raise ValueError("level sizes must have n_bits entries")
+    arr = (C.c_int32 * n_bits)(*[int(s) for s in sizes])
+    return arr, C.cast(arr, C.c_void_p)
+
+
+def pack_matryoshka(w: torch.Tensor, wm: torch.Tensor, n_bits: int, abs_range: float, sizes=None):
+    """-> (codes int32 [D, ceil(H/16)] of S/2, scale fp32 [H])."""
     w, wm = _f32c(w, "w"), _f32c(wm, "wm")
     H, D = w.shape
     codes = torch.empty((D, (H + 15) // 16), dtype=torch.int32, device=w.device)
     scale = torch.empty((H,), dtype=torch.float32, device=w.device)
-    check(_lib.load().qsae_pack_matryoshka(_p(w), _p(wm), H, D, n_bits, float(abs_range), _p(codes), _p(scale),
+    keep, sp = _sizes_arg(sizes, n_bits)
+    check(_lib.load().qsae_pack_matryoshka(_p(w), _p(wm), H, D, n_bits, float(abs_range), sp, _p(codes), _p(scale),
                                            _stream()))
     return codes, scale
 
 
-def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, scale, bias, allow_bias: bool):
+def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, scale, bias, allow_bias: bool,
+                      sizes=None):
     """-> (levels f32 [n_bits, B, D], l0_counts int64 [n_bits])."""
     _dev(zbits, "zbits", torch.int32)
     B = zbits.shape[0]
     levels = torch.empty((n_bits, B, D), dtype=torch.float32, device=zbits.device)
     counts = torch.zeros((n_bits,), dtype=torch.int64, device=zbits.device)
     b = _f32c(bias, "bias") if bias is not None else None
+    keep, sp = _sizes_arg(sizes, n_bits)
     check(_lib.load().qsae_decode_matryoshka(_p(zbits), zbits.stride(0) if B else (H + 31) // 32, B, H, D, n_bits,
-                                             _p(codes), _p(scale), _p(b), 1 if allow_bias else 0, _p(levels),
+                                             sp, _p(codes), _p(scale), _p(b), 1 if allow_bias else 0, _p(levels),
                                              _p(counts), _stream()))
     return levels, counts
+
+
+def pack_bits_gt(dense: torch.Tensor, thr: float) -> torch.Tensor:
+    """int32-packed bits [B, ceil(H/32)] of (dense > thr)."""
+    _dev(dense, "dense", torch.float32)
+    if dense.stride(1) != 1:
+        dense = dense.contiguous()
+    B, H = dense.shape
+    words = (H + 31) // 32
+    z = torch.empty((B, words), dtype=torch.int32, device=dense.device)
+    check(_lib.load().qsae_pack_bits_gt(_p(dense), dense.stride(0) if B else H, B, H, float(thr), _p(z), words,
+                                        _stream()))
+    return z
 
 
 # ---- metric ------------------------------------------------------------------------------------

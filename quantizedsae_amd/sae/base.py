@@ -1,0 +1,100 @@
+"""Base class and shared plumbing (reference: sae/base.py:5-29)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class HipEncoder(nn.Sequential):
+    """``nn.Sequential(nn.Linear[, activation])`` whose forward is one HIP kernel.
+
+    Keeping the Sequential container preserves the reference's state_dict keys
+    (``encoder.0.weight`` / ``encoder.0.bias``) and lets callers keep invoking
+    ``model.encoder(x)`` (scripts/analysis/dynamic_analysis.py:51); the contraction, bias and
+    activation run in ``qsae_encode_dense`` instead of ATen.
+    """
+
+    def __init__(self, linear: nn.Linear, activation: Optional[nn.Module] = None):
+        mods = [linear] + ([activation] if activation is not None else [])
+        super().__init__(*mods)
+        if activation is None:
+            self._act = ops.ACT_NONE
+        elif isinstance(activation, nn.ReLU):
+            self._act = ops.ACT_RELU
+        elif isinstance(activation, nn.Sigmoid):
+            self._act = ops.ACT_SIGMOID
+        else:
+            raise TypeError(f"unsupported encoder activation {type(activation)}")
+
+    @property
+    def linear(self) -> nn.Linear:
+        return self[0]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
+        with torch.no_grad():
+            return ops.encode_dense(x, self[0].weight, self[0].bias, self._act)
+
+
+class PackedCache:
+    """Derived (packed) weights keyed on the source parameters' identity and version counter, so
+    that load_state_dict / .to(device) / in-place edits invalidate them automatically."""
+
+    def __init__(self):
+        self._key = None
+        self._value = None
+
+    @staticmethod
+    def _sig(tensors) -> Tuple:
+        return tuple((t.data_ptr(), t._version, str(t.device), tuple(t.shape)) for t in tensors)
+
+    def get(self, tensors, build: Callable[[], Dict]):
+        key = self._sig(tensors)
+        if key != self._key:
+            self._value = build()
+            self._key = key
+        return self._value
+
+    def clear(self):
+        self._key = None
+        self._value = None
+
+
+class SparseAutoencoder(nn.Module):
+    """encode -> decode -> (latent, reconstruction); subclasses install encoder/decoder."""
+
+    def __init__(self, input_dim: int, hidden_dim: int):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.encoder = None
+        self.decoder = None
+
+    def encode(self, x):
+        if self.encoder is None:
+            raise NotImplementedError("Encoder has not been implemented.")
+        return self.encoder(x)
+
+    def decode(self, h):
+        if self.decoder is None:
+            raise NotImplementedError("Decoder has not been implemented.")
+        return self.decoder(h)
+
+    def forward(self, x):
+        latent = self.encode(x)
+        return latent, self.decode(latent)
+
+
+def require_device_input(x: torch.Tensor, what: str = "input") -> torch.Tensor:
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{what}: expected a torch.Tensor, got {type(x)}")
+    if not x.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {x.device}: quantizedsae_amd computes on MI355X only and has no CPU fallback; "
+            "move the model and the batch to a ROCm device")
+    if x.dim() != 2:
+        raise ValueError(f"{what}: expected a [batch, features] tensor, got shape {tuple(x.shape)}")
+    return x

@@ -1,0 +1,52 @@
+"""BaselineSparseAutoencoder: Linear -> top-32 -> Linear (reference: sae/baseline.py:4-51)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .base import HipEncoder, PackedCache, require_device_input
+
+
+class BaselineSparseAutoencoder(nn.Module):
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.encoder = HipEncoder(nn.Linear(input_dim, hidden_dim))   # no ReLU in the reference either
+        self.decoder = nn.Linear(hidden_dim, input_dim)
+        self.topk = 32
+        self._cache = PackedCache()
+
+    def _table(self) -> torch.Tensor:
+        # decoder.weight is [D, H]; the sparse decode gathers rows of its transpose [H, D]
+        return self._cache.get((self.decoder.weight,),
+                               lambda: {"t": self.decoder.weight.detach().t().contiguous()})["t"]
+
+    def forward(self, x):
+        """-> (h_sparse [B,H], recon [B,D])  (sae/baseline.py:17-31)."""
+        with torch.no_grad():
+            x = require_device_input(x, "x")
+            lin = self.encoder.linear
+            h = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
+            idx, val = ops.topk_rows(h, self.topk, zero_rest=True)
+            recon = ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
+            return h, recon
+
+    def forward_compact(self, x):
+        with torch.no_grad():
+            x = require_device_input(x, "x")
+            lin = self.encoder.linear
+            idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.topk)
+            return idx, val, ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
+
+    def apply_topk_activation(self, h):
+        """Dense in, dense out: keep the top-k entries of every row (sae/baseline.py:33-40)."""
+        with torch.no_grad():
+            out = require_device_input(h, "h").float().clone()
+            ops.topk_rows(out, self.topk, zero_rest=True)
+            return out
+
+    def normalize_decoder_weights(self):
+        """Unit-norm decoder columns (sae/baseline.py:42-51; training utility, plain torch ops)."""
+        with torch.no_grad():
+            w = self.decoder.weight.data
+            self.decoder.weight.data = w / torch.clamp(torch.norm(w, dim=0, keepdim=True), min=1e-8)

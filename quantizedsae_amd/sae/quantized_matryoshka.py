@@ -1,0 +1,179 @@
+"""QuantizedMatryoshkaSAE: sigmoid encoder binarised at 0.5, nested {-2,0,+2} dictionaries with
+per-row scales (reference: sae/quantized_matryoshka.py:10-220)."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .base import HipEncoder, PackedCache, SparseAutoencoder, require_device_input
+
+_TRAINING_ONLY = ("the secant-gradient correction belongs to the reference's training loop "
+                  "(sae/quantized_matryoshka.py:145-190) and is outside this inference backend")
+
+
+def nested_sizes(in_features: int, n_bits: int) -> List[int]:
+    """Level sizes [1,1,2,4,...] scaled to in_features, remainder in the last level
+    (sae/quantized_matryoshka.py:25-38)."""
+    sizes = [1 if i < 2 else 2 ** (i - 1) for i in range(n_bits)]
+    total = sum(sizes)
+    if total != in_features:
+        f = in_features / total
+        sizes = [max(1, int(s * f)) for s in sizes]
+        sizes[-1] = in_features - sum(sizes[:-1])
+    return sizes
+
+
+def _pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+class QuantizedMatryoshkaDecoder(nn.Module):
+    """``forward(latent [B,H]) -> (latent_group: list of n 0-d tensors, result: list of n [B,D])``.
+
+    Level i covers a slice of the hidden units; S = sgn(sigmoid(w) >= .5) + sgn(sigmoid(wm) >= .5),
+    scale_j = 2^(n-i-2) * quant_step / (||S_j|| + 1e-8), z = latent > 0.5,
+    recon_i = recon_{i-1} + (scale * z) @ S (+ bias once, after level 0).
+
+    The packed form keeps S/2 as 2-bit fields (hidden index contiguous) and fp32 scales; the kernels
+    need every level boundary on a multiple of 32, so odd level sizes are padded with inert units
+    (S = 0, z = 0) at pack time.
+    """
+
+    def __init__(self, in_features, out_features, abs_range=4, n_bits=8, top_k=None, joint_gradient=False,
+                 allow_bias=True):
+        super().__init__()
+        self._ctx = [None] * n_bits
+        self.joint_gradient = joint_gradient
+        self.in_features = in_features
+        self.out_features = out_features
+        self.n_bits = n_bits
+        self.abs_range = abs_range
+        self.quant_step = abs_range / (2 ** (n_bits - 1))
+        self.top_k = top_k
+        self.allow_bias = allow_bias
+        self.nested_dictionary_size = nested_sizes(in_features, n_bits)
+        self.weight = nn.Parameter(torch.empty(in_features, out_features))
+        self.weight_mirror = nn.Parameter(torch.empty(in_features, out_features))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+        nn.init.xavier_uniform_(self.weight)
+        nn.init.xavier_uniform_(self.weight_mirror)
+        self._cache = PackedCache()
+
+    # -- layout ---------------------------------------------------------------------------------
+    @property
+    def padded_sizes(self) -> List[int]:
+        return [_pad32(s) for s in self.nested_dictionary_size]
+
+    @property
+    def needs_padding(self) -> bool:
+        return self.padded_sizes != list(self.nested_dictionary_size)
+
+    def padded_index(self, device) -> torch.Tensor:
+        """For every padded hidden slot the source hidden unit, or -1 for an inert pad slot."""
+        out = []
+        start = 0
+        for s, p in zip(self.nested_dictionary_size, self.padded_sizes):
+            out.append(torch.arange(start, start + s, device=device))
+            if p > s:
+                out.append(torch.full((p - s,), -1, device=device, dtype=torch.long))
+            start += s
+        return torch.cat(out)
+
+    def packed(self) -> dict:
+        def build():
+            w = require_device_input(self.weight.detach(), "decoder.weight")
+            wm = self.weight_mirror.detach()
+            sizes = list(self.nested_dictionary_size)
+            st = {"sizes": sizes, "H": self.in_features, "index": None}
+            if self.needs_padding:
+                index = self.padded_index(w.device)
+                valid = index >= 0
+                Hp = int(index.numel())
+                wp = torch.ones((Hp, self.out_features), device=w.device)
+                wmp = -torch.ones((Hp, self.out_features), device=w.device)   # S = 0 on pad rows
+                wp[valid] = w[index[valid]]
+                wmp[valid] = wm[index[valid]]
+                w, wm = wp, wmp
+                st.update(sizes=self.padded_sizes, H=Hp, index=index)
+            codes, scale = ops.pack_matryoshka(w, wm, self.n_bits, self.abs_range, st["sizes"])
+            st.update(codes=codes, scale=scale)
+            return st
+        return self._cache.get((self.weight, self.weight_mirror), build)
+
+    # -- decode ---------------------------------------------------------------------------------
+    def decode_bits(self, zbits: torch.Tensor) -> Tuple[list, list]:
+        """zbits: int32-packed [B, H_padded/32] in the packed (padded) hidden order."""
+        st = self.packed()
+        B = zbits.shape[0]
+        levels, counts = ops.decode_matryoshka(zbits, st["H"], self.out_features, self.n_bits, st["codes"],
+                                               st["scale"], self.bias.detach(), self.allow_bias, st["sizes"])
+        groups = (counts.to(torch.float64) / max(B, 1)).to(torch.float32)
+        return [groups[i] for i in range(self.n_bits)], [levels[i] for i in range(self.n_bits)]
+
+    def forward(self, latent):
+        with torch.no_grad():
+            latent = require_device_input(latent, "latent")
+            if latent.dtype != torch.float32:
+                latent = latent.float()
+            st = self.packed()
+            if st["index"] is not None:
+                index = st["index"]
+                padded = torch.zeros((latent.shape[0], st["H"]), device=latent.device)
+                padded[:, index >= 0] = latent[:, index[index >= 0]]
+                latent = padded
+            return self.decode_bits(ops.pack_bits_gt(latent, 0.5))
+
+    def apply_secant_grad(self):
+        raise NotImplementedError(_TRAINING_ONLY)
+
+
+class QuantizedMatryoshkaSAE(SparseAutoencoder):
+    """``forward(x) -> (latent_groups, reconstruction_levels)``; ``top_k`` is stored and unused, as
+    in the reference (sae/quantized_matryoshka.py:192-220)."""
+
+    def __init__(self, input_dim, hidden_dim, top_k, abs_range=4, n_bits=8, allow_bias=True):
+        super().__init__(input_dim, hidden_dim)
+        self.n_bits = n_bits
+        self.abs_range = abs_range
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.allow_bias = allow_bias
+        self.top_k = top_k
+        lin = nn.Linear(input_dim, hidden_dim)
+        nn.init.xavier_uniform_(lin.weight, gain=1)
+        nn.init.zeros_(lin.bias)
+        self.encoder = HipEncoder(lin, nn.Sigmoid())
+        self.decoder = QuantizedMatryoshkaDecoder(hidden_dim, input_dim, abs_range=abs_range, n_bits=n_bits,
+                                                  top_k=self.top_k, allow_bias=self.allow_bias)
+        self._enc_cache = PackedCache()
+
+    def _encoder_params(self):
+        """Encoder weight/bias in the decoder's packed hidden order (inert pad units get a zero row
+        and bias -1, so their z bit is 0)."""
+        lin = self.encoder.linear
+        if not self.decoder.needs_padding:
+            return lin.weight.detach(), lin.bias.detach()
+
+        def build():
+            index = self.decoder.padded_index(lin.weight.device)
+            valid = index >= 0
+            W = torch.zeros((index.numel(), self.input_dim), device=lin.weight.device)
+            b = -torch.ones((index.numel(),), device=lin.weight.device)
+            W[valid] = lin.weight.detach()[index[valid]]
+            b[valid] = lin.bias.detach()[index[valid]]
+            return {"W": W, "b": b}
+        st = self._enc_cache.get((lin.weight, lin.bias), build)
+        return st["W"], st["b"]
+
+    def activation_bits(self, x) -> torch.Tensor:
+        """int32-packed z = (sigmoid(encoder pre-activation) > 0.5) in packed hidden order."""
+        with torch.no_grad():
+            W, b = self._encoder_params()
+            return ops.encode_bits(require_device_input(x, "x"), W, b)
+
+    def forward(self, x):
+        with torch.no_grad():
+            return self.decoder.decode_bits(self.activation_bits(x))

@@ -1,0 +1,75 @@
+"""TernarySparseAutoencoder: ReLU encoder, {-1,0,+1} dictionary (reference: sae/ternary.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .base import HipEncoder, PackedCache, require_device_input
+
+_TRAINING_ONLY = ("RigL mask maintenance is part of the reference's training loop "
+                  "(sae/ternary.py:27-39,54-90) and is outside this inference backend")
+
+
+class STEWeights(nn.Module):
+    """Ternary dictionary ``hard = sign(w) * (|w| >= threshold)``, no bias (sae/ternary.py:41-52).
+    The straight-through expression of the reference evaluates to exactly ``hard`` and does not
+    depend on ``mask``; the 2-bit packed codes are derived from ``weight`` alone."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.threshold = 0.5
+        self.register_buffer("mask", torch.ones(out_features, in_features))
+        self.input_activations = None   # the reference pins the last [B,H] input here; not kept
+        self.output_grad = None
+        nn.init.kaiming_normal_(self.weight)
+        self._cache = PackedCache()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # checkpoints saved by the reference after a forward carry these hook buffers
+        for name in ("input_activations", "output_grad"):
+            state_dict.pop(prefix + name, None)
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def codes(self) -> torch.Tensor:
+        if self.threshold != 0.5:
+            raise NotImplementedError("only the reference threshold 0.5 is packed")
+        return self._cache.get((self.weight,), lambda: {"c": ops.pack_ternary(self.weight.detach())})["c"]
+
+    def forward(self, x):
+        with torch.no_grad():
+            x = require_device_input(x, "x")
+            if x.dtype != torch.float32 or x.stride(1) != 1:
+                x = x.float().contiguous()
+            return ops.decode_ternary_dense(x, self.codes(), self.weight.shape[0])
+
+    def init_mask(self, sparsity):
+        raise NotImplementedError(_TRAINING_ONLY)
+
+    def update_mask(self, f_decay, sparsity_rate=0.7):
+        raise NotImplementedError(_TRAINING_ONLY)
+
+    def mask_grad(self):
+        raise NotImplementedError(_TRAINING_ONLY)
+
+
+class TernarySparseAutoencoder(nn.Module):
+    """``forward(x) -> (h [B,H], recon [B,D])``; no top-k in forward (sae/ternary.py:116-122)."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.encoder = HipEncoder(nn.Linear(input_dim, hidden_dim), nn.ReLU())
+        self.decoder = STEWeights(hidden_dim, input_dim)
+        self.topk = int(hidden_dim * 0.002)
+
+    def apply_topk_activation(self, h):
+        """Top-k of each row with non-positive survivors zeroed (sae/ternary.py:102-114)."""
+        with torch.no_grad():
+            out = require_device_input(h, "h").float().clone()
+            ops.topk_rows(out, self.topk, zero_rest=True)
+            return torch.clamp_(out, min=0)
+
+    def forward(self, x):
+        h = self.encoder(require_device_input(x, "x"))
+        return h, self.decoder(h)

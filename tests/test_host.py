@@ -1,0 +1,226 @@
+"""Host-side logic and the C-ABI surface; runs without a GPU."""
+import ctypes
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from quantizedsae_amd import (BaselineSparseAutoencoder, BinarySAE, QuantizedMatryoshkaSAE, ResidualQuantizedSAE,
+                              SparseAutoencoder, TernarySparseAutoencoder, _lib, sharding)
+from quantizedsae_amd.inference import framework as F
+from quantizedsae_amd.sae.quantized_matryoshka import nested_sizes
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+# ---- C ABI --------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+    declared = ge.declared_symbols()
+    assert len(declared) >= 20 and "qsae_encode_dense" in declared
+    assert _lib.LIB_PATH.exists(), "build with `python -m quantizedsae_amd.build`"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_lib.SIGNATURES) == declared          # the ctypes table binds exactly the header
+    assert _lib.load().qsae_abi_version() == 1
+
+
+def test_host_side_entry_points():
+    lib = _lib.load()
+    assert lib.qsae_binary_row_bytes(512, 4) == 256
+    assert lib.qsae_binary_row_bytes(512, 8) == 512
+    assert lib.qsae_binary_row_bytes(20, 3) == 12          # 20 nibbles = 80 bits -> 3 dwords
+    assert lib.qsae_binary_row_bytes(0, 4) == _lib.ERR_INVALID_ARG
+    assert lib.qsae_binary_row_bytes(512, 9) == _lib.ERR_INVALID_ARG
+    for H, n in [(32768, 4), (1000, 4), (4096, 1), (1100, 4), (97, 3)]:
+        arr = (ctypes.c_int32 * n)()
+        assert lib.qsae_matryoshka_sizes(H, n, ctypes.cast(arr, ctypes.c_void_p)) == 0
+        assert list(arr) == oracle.matryoshka_sizes(H, n) == nested_sizes(H, n)
+    assert lib.qsae_matryoshka_sizes(0, 4, None) == _lib.ERR_INVALID_ARG
+    assert b"invalid argument" in lib.qsae_last_error()
+    # B == 0 is a no-op that needs no device
+    assert lib.qsae_encode_dense(None, None, None, 0, 512, 32768, 0, None, 32768, None) == 0
+    assert lib.qsae_topk_rows(None, 32768, 0, 32768, 65, None, None, 1, None) == 0
+    # argument validation happens before any HIP call
+    assert lib.qsae_encode_dense(None, None, None, 4, 512, 32768, 0, None, 32768, None) == _lib.ERR_INVALID_ARG
+    assert lib.qsae_topk_rows(ctypes.c_void_p(16), 32768, 1, 32768, 300, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                              1, None) == _lib.ERR_UNSUPPORTED
+    assert lib.qsae_encode_topk_workspace_bytes(65536, 512, 32768, 65) == 1024 * 32768 * 4
+
+
+def test_no_cpu_fallback():
+    m = BinarySAE(64, 512, gamma=4.0, n_bits=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(2, 64))
+    with pytest.raises(RuntimeError):
+        BaselineSparseAutoencoder(64, 512)(torch.zeros(2, 64))
+    with pytest.raises(RuntimeError):
+        TernarySparseAutoencoder(64, 512)(torch.zeros(2, 64))
+    with pytest.raises(RuntimeError):
+        QuantizedMatryoshkaSAE(64, 512, 32, n_bits=4)(torch.zeros(2, 64))
+    with pytest.raises(TypeError):
+        m([1, 2, 3])
+
+
+# ---- module face ----------------------------------------------------------------------------------
+def _shapes(m):
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_state_dict_contract():
+    D, H, n = 512, 2048, 4
+    assert _shapes(BinarySAE(D, H, gamma=4.0, n_bits=n)) == {
+        "encoder.0.weight": (H, D), "encoder.0.bias": (H,), "decoder.weight": (H, D * n), "decoder.bias": (D,)}
+    assert _shapes(BaselineSparseAutoencoder(D, H)) == {
+        "encoder.0.weight": (H, D), "encoder.0.bias": (H,), "decoder.weight": (D, H), "decoder.bias": (D,)}
+    assert _shapes(TernarySparseAutoencoder(D, H)) == {
+        "encoder.0.weight": (H, D), "encoder.0.bias": (H,), "decoder.weight": (D, H), "decoder.mask": (D, H)}
+    assert _shapes(QuantizedMatryoshkaSAE(D, H, 32, n_bits=n)) == {
+        "encoder.0.weight": (H, D), "encoder.0.bias": (H,), "decoder.weight": (H, D),
+        "decoder.weight_mirror": (H, D), "decoder.bias": (D,)}
+    rq = ResidualQuantizedSAE(D, H, 32, n_bits=n)
+    assert rq.sae_hidden_dims == [256, 256, 512, 1024]
+    keys = set(rq.state_dict())
+    for i in range(n):
+        for k in ("encoder.0.weight", "encoder.0.bias", "decoder.weight", "decoder.weight_mirror", "decoder.bias"):
+            assert f"saes.{i}.{k}" in keys
+
+
+def test_constructor_attributes():
+    b = BinarySAE(512, 32768, gamma=4.0, n_bits=4)
+    assert (b.n_bits, b.input_dim, b.hidden_dim, b.k, b.top_k) == (4, 512, 32768, 0.002, 65)
+    assert b.decoder.quantization_step == 0.5 and b.decoder.in_features == 32768 and b.decoder.n_bits == 4
+    assert BinarySAE(512, 32768, gamma=1.5, n_bits=4).decoder.quantization_step == 0.1875
+    assert BinarySAE(8, 16).n_bits == 8                                  # reference default
+    assert float(b.encoder[0].bias.detach().abs().sum()) == 0.0
+    assert float(b.encoder[0].weight.detach().abs().max()) <= (6 / (512 + 32768)) ** 0.5 * (1 + 1e-6)
+    assert BaselineSparseAutoencoder(512, 1024).topk == 32
+    t = TernarySparseAutoencoder(512, 32768)
+    assert t.topk == 65 and t.decoder.threshold == 0.5
+    q = QuantizedMatryoshkaSAE(512, 32768, top_k=32, abs_range=4, n_bits=4)
+    assert q.decoder.nested_dictionary_size == [4096, 4096, 8192, 16384]
+    assert q.decoder.quant_step == 0.5 and q.top_k == 32 and not q.decoder.needs_padding
+    odd = QuantizedMatryoshkaSAE(64, 1000, top_k=32, n_bits=4)
+    assert odd.decoder.nested_dictionary_size == [125, 125, 250, 500]
+    assert odd.decoder.padded_sizes == [128, 128, 256, 512] and odd.decoder.needs_padding
+    idx = odd.decoder.padded_index("cpu")
+    assert idx.numel() == 1024 and (idx >= 0).sum() == 1000
+    assert torch.equal(idx[idx >= 0], torch.arange(1000))
+    base = SparseAutoencoder(4, 8)
+    with pytest.raises(NotImplementedError):
+        base.encode(torch.zeros(1, 4))
+    with pytest.raises(NotImplementedError):
+        base.decode(torch.zeros(1, 8))
+
+
+def test_ternary_checkpoint_with_hook_buffers_loads():
+    m = TernarySparseAutoencoder(16, 64)
+    sd = dict(m.state_dict())
+    sd["decoder.input_activations"] = torch.zeros(3, 64)     # what the reference saves after a forward
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(NotImplementedError):
+        m.decoder.update_mask(0.1)
+
+
+# ---- wrapper face ------------------------------------------------------------------------------------
+def test_registry_and_loader_errors(tmp_path):
+    assert list(F.SAE_REGISTRY)[:4] == ["b_sae", "q_sae", "rq_sae", "baseline_sae"]
+    assert F.SAE_REGISTRY["b_sae"].kwargs == {"input_dim": 512, "hidden_dim": 32768, "gamma": 1.5, "n_bits": 4}
+    assert F.SAE_REGISTRY["q_sae"].kwargs["abs_range"] == 1.5 and F.SAE_REGISTRY["q_sae"].kwargs["top_k"] == 32
+    assert set(F.available_saes()) == set(F.SAE_REGISTRY)
+    assert all(isinstance(p, Path) for p in F.available_saes().values())
+    with pytest.raises(KeyError):
+        F.load_sae("nope")
+    with pytest.raises(FileNotFoundError):
+        F.load_sae("b_sae")
+    with pytest.raises(ValueError):
+        F._ensure_tensor([])
+    with pytest.raises(TypeError):
+        F._ensure_tensor(np.zeros(3))
+    t = torch.zeros(2)
+    assert F._ensure_tensor((t, 1)) is t
+    assert F._default_device("cpu") == torch.device("cpu")
+
+
+def test_eleuther_safetensors_remap(tmp_path):
+    from safetensors.torch import save_file
+    H, D = 32, 8
+    raw = {"encoder.weight": torch.randn(H, D), "encoder.bias": torch.randn(H), "W_dec": torch.randn(H, D),
+           "b_dec": torch.randn(D)}
+    p = tmp_path / "sae.safetensors"
+    save_file(raw, str(p))
+    import dataclasses
+    entry = dataclasses.replace(F.SAE_REGISTRY["baseline_sae"], checkpoint_path=p, checkpoint_format="safetensors",
+                                kwargs={"input_dim": D, "hidden_dim": H})
+    sd = F._load_state_dict(entry)
+    assert torch.equal(sd["decoder.weight"], raw["W_dec"].t()) and sd["decoder.weight"].shape == (D, H)
+    BaselineSparseAutoencoder(D, H).load_state_dict(sd, strict=True)
+
+
+# ---- sharding ------------------------------------------------------------------------------------------
+def test_shard_rows_partitions_exactly():
+    for n in [0, 1, 7, 64, 65536, 10_000_000, 10_000_001]:
+        for ws in [1, 2, 3, 8]:
+            spans = [sharding.shard_rows(n, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_rows(10, 2, 2)
+    chunks = list(sharding.iter_chunk_shards([10_000_000, 5], 8, 3))
+    assert chunks[0] == (0, 3_750_000, 5_000_000) and chunks[1] == (1, 3, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quantizedsae_amd import synthetic as S
+    n_rows, D = 1001, 16
+    x = S.normal(1, (n_rows, D), stream=1)
+    recon = x + S.normal(1, (n_rows, D), stream=2, std=0.1)
+    s, e = sharding.shard_rows(n_rows, world, rank)
+    part = oracle.sq_err_sum(recon[s:e], x[s:e])                  # each rank reduces only its own rows
+    mse = sharding.reduce_mse(torch.tensor(part, dtype=torch.float64), (e - s) * D)
+    slow = sharding.max_over_ranks(1.0 + rank)
+    q.put((rank, mse, slow, (s, e)))
+    dist.destroy_process_group()
+
+
+def test_row_sharded_mse_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from quantizedsae_amd import synthetic as S
+    x = S.normal(1, (1001, 16), stream=1)
+    recon = x + S.normal(1, (1001, 16), stream=2, std=0.1)
+    want = oracle.sq_err_sum(recon, x) / x.size
+    assert res[0][3] == (0, 501) and res[1][3] == (501, 1001)
+    for _, mse, slow, _ in res:
+        assert mse == pytest.approx(want, rel=1e-12)
+        assert slow == 2.0

@@ -157,3 +157,22 @@ def test_topk_order_and_ties():
     idx, val = oracle.topk(lat, 2)
     assert idx.tolist() == [[0, 1], [0, 1], [0, 3]]      # (value desc, index asc); NaN ranks first
     assert int(32768 * 0.002) == 65 and np.float32(4.0 / 2 ** 3) == 0.5
+
+
+@pytest.mark.parametrize("name", ["binary_small", "binary_mid"])
+def test_torch_restatement_matches_reference(name):
+    """The op-sequence restatement timed as cpu_baseline reproduces the reference's outputs."""
+    import torch
+    from oracle import torch_restatement as T
+    fx = Fixture(name)
+    m = fx.meta
+    sd = {k: torch.from_numpy(v) for k, v in fx.state_dict().items()}
+    x = torch.from_numpy(fx.x())
+    sparse, recon, pol = T.binary_forward(x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                          sd["decoder.bias"], n_bits=m["n_bits"], gamma=m["gamma"], k=m["k"])
+    assert rel_err(recon.numpy(), fx["reconstruction"]) < 1e-6
+    assert float(pol) == pytest.approx(float(fx["polarize_loss"]), rel=1e-6, abs=1e-20)
+    nz = sparse.numpy() != 0
+    assert (nz.sum(axis=1) == m["k"]).all()
+    got_idx = np.stack([np.nonzero(r)[0] for r in nz]).astype(np.int32)
+    assert np.array_equal(got_idx, fx["topk_idx"])
