@@ -38,6 +38,9 @@ template <int BM, int BN>
 struct EpiStore {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
+    static constexpr int kLdsFloats = 0;
+    template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
+    template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {
         float* out;
         int64_t ld;
@@ -51,7 +54,7 @@ struct EpiStore {
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
     }
     __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
-    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c, float*) {
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -120,6 +123,9 @@ template <int BM, int BN>
 struct EpiLevels {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 1;
+    static constexpr int kLdsFloats = 0;
+    template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
+    template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {
         LevelTable lv;
         const float* bias;     // nullptr when allow_bias == 0
@@ -158,7 +164,7 @@ struct EpiLevels {
         for (int i = 0; i < a.lv.n; ++i)
             if (a.lv.end[i] == k_done) write_level(a, acc, c, i);
     }
-    __device__ __forceinline__ void finish(const Args&, f32x16 (&)[MT][NT], const TileCtx&, float*) {}
+    __device__ __forceinline__ void finish(const Args&, f32x16 (&)[MT][NT], const TileCtx&) {}
 };
 
 // l0_counts[level] += popcount of the level's z bits (level boundaries multiples of 32)
@@ -254,13 +260,13 @@ static int run_ternary(const float* h, int64_t ld, int B, int H, const uint32_t*
         using LB = LoaderCode2<BN, BK, false>;
         typename LA::Args la{h, ld, B};
         typename LB::Args lb{codes, words, D};
-        return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, s);
+        return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, pick_sweep<BM, BN>(B, D, H), s);
     }
     using LA = LoaderF32<BM, BK, true>;
     using LB = LoaderCode2<BN, BK, true>;
     typename LA::Args la{h, ld, B};
     typename LB::Args lb{codes, words, D};
-    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, s);
+    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, pick_sweep<BM, BN>(B, D, H), s);
 }
 
 extern "C" int qsae_decode_ternary_dense(const float* h, int64_t ld, int B, int H, const uint32_t* codes2, int D,
@@ -304,7 +310,7 @@ static int run_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H,
     using LB = LoaderCode2<BN, BK, false, 2>;   // fields hold S/2
     typename LA::Args la{zbits, words_ld, B, scale2};
     typename LB::Args lb{codes, (H + 15) / 16, D};
-    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, s);
+    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, D, H, pick_sweep<BM, BN>(B, D, H), s);
 }
 
 extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,

@@ -11,6 +11,7 @@
 namespace qsae {
 
 static int g_gemm_config = 0;   // 0 = auto, 1 = 256x256x32, 2 = 128x128x32, 3 = 256x256x16
+int g_sweep_override = 0;       // 0 = heuristic (pick_sweep)
 
 // ---- epilogues ------------------------------------------------------------------------
 template <int MT, int NT, int WTM, int WTN>
@@ -34,6 +35,9 @@ template <int ACT, int BM, int BN>
 struct EpiDense : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
+    static constexpr int kLdsFloats = 0;
+    template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
+    template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {
         const float* bias;
         float* out;
@@ -43,7 +47,7 @@ struct EpiDense : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
         this->seed_bias(a.bias, acc, c);
     }
     __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
-    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c, float*) {
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -68,6 +72,9 @@ template <int BM, int BN>
 struct EpiBits : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
+    static constexpr int kLdsFloats = 0;
+    template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
+    template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {
         const float* bias;
         uint32_t* zbits;
@@ -77,7 +84,7 @@ struct EpiBits : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
         this->seed_bias(a.bias, acc, c);
     }
     __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
-    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c, float*) {
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -107,13 +114,13 @@ static int run_encoder(const float* x, const float* W, int B, int D, int H, cons
         using LB = LoaderF32<BN, BK, false>;
         typename LA::Args la{x, D, B};
         typename LB::Args lb{W, D, H};
-        return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, H, D, s);
+        return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, H, D, pick_sweep<BM, BN>(B, H, D), s);
     }
     using LA = LoaderF32<BM, BK, true>;
     using LB = LoaderF32<BN, BK, true>;
     typename LA::Args la{x, D, B};
     typename LB::Args lb{W, D, H};
-    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, H, D, s);
+    return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, H, D, pick_sweep<BM, BN>(B, H, D), s);
 }
 
 template <int ACT, int BM, int BN, int BK>
@@ -136,8 +143,8 @@ static int run_bits(const float* x, const float* W, const float* bias, int B, in
 // chip (>= 256 tiles), otherwise 128x128 for more workgroups.
 static int pick_config(int M, int N) {
     if (g_gemm_config) return g_gemm_config;
-    const long long t256 = static_cast<long long>((M + 255) / 256) * ((N + 255) / 256);
-    return t256 >= 256 ? 1 : 2;
+    (void)M; (void)N;
+    return 2;   // 128x128x32 at two workgroups per CU measured fastest (profiles/r01_*)
 }
 
 template <int ACT>
@@ -156,6 +163,11 @@ using namespace qsae;
 
 extern "C" int qsae_debug_set_gemm_config(int cfg) {
     g_gemm_config = cfg;
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_set_sweep(int sweep) {
+    g_sweep_override = sweep;
     return QSAE_OK;
 }
 

@@ -1,22 +1,336 @@
 // encode_topk.hip -- encoder + per-row top-k without a [B, H] latent in HBM.
 //
 // Replaces `latent = encode(x); latent.topk(k)` (reference sae/binary.py:93-94,
-// sae/baseline.py:22-35).  Current form: the batch is walked in row chunks whose dense latent
-// (chunk x H fp32) stays in a small workspace that fits the 256 MiB Infinity Cache; each
-// chunk is contracted by the exact-fp32 MFMA kernel and reduced to (idx, val) by the top-k
-// kernel before the next chunk overwrites the workspace.  Results are identical to
-// qsae_encode_dense + qsae_topk_rows.
-#include "common.h"
+// sae/baseline.py:22-35).  Results are identical to qsae_encode_dense + qsae_topk_rows.
+//
+// Fused form (large batches):
+//   1. pilot   : the first P hidden units are contracted densely ([B, P], P = H/16) and a per-row
+//                threshold tau = j-th largest pilot value is taken (j = 20).  tau is a valid lower
+//                bound of the row's k-th largest latent as long as fewer than j of the row's top-k
+//                live in the pilot block (hypergeometric, mean k/16; for exchangeable hidden units
+//                the chance of >= 20 is ~1e-8) -- and validity is CHECKED, not assumed (step 3).
+//   2. sweep   : every workgroup owns 128 activation rows and sweeps all remaining hidden tiles
+//                with the exact-fp32 MFMA kernel (hidden units on accumulator registers, rows on
+//                lanes); the epilogue compares each accumulator with its row's tau (one v_cmp per
+//                value) and appends the few survivors (~1 %) to that row's candidate list.
+//   3. select  : one wave per row picks the exact top-k of the candidates with a 48-step
+//                ballot radix select on (value, index) keys.  A row with fewer than k candidates
+//                (tau was not a lower bound) or an overflowing list is flagged ...
+//   4. fallback: ... and flagged rows (normally none) are recomputed by the unfused kernels.
+// Small problems use the chunked two-kernel form directly.
+#include <vector>
+
+#include "gemm_mfma_f32.h"
 
 namespace qsae {
-constexpr int kChunkRows = 1024;   // 1024 x 32768 x 4 B = 128 MiB of latent per chunk
+
+int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
+                       float* tau, uint2* cand, int* cnt, int cap, hipStream_t s);
+
+constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
+constexpr int kCandCap = 1024;     // candidate slots per row
+constexpr int kPilotRank = 20;     // tau = kPilotRank-th largest pilot value
+constexpr int kFusedMinRows = 2048;
+constexpr int kFusedMinHidden = 8192;
+static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static bool use_fused(int B, int D, int H, int k) {
+    if (g_force_path == 1) return false;
+    const bool shape_ok = (H % 4 == 0) && (H / 16 >= 256) && k <= 256 && H <= 65536;
+    if (g_force_path == 2) return shape_ok;
+    return shape_ok && B >= kFusedMinRows && H >= kFusedMinHidden;
 }
+
+static int pilot_width(int H) {
+    int p = H / 16;
+    p = (p + 127) / 128 * 128;
+    return p;
+}
+
+struct FusedLayout {
+    size_t pilot, tau, cnt, cand, flags, fx, flat, fidx, fval, total;
+};
+
+static FusedLayout fused_layout(int B, int D, int H, int k) {
+    FusedLayout L;
+    const int P = pilot_width(H);
+    size_t off = 0;
+    L.pilot = off; off = align_up(off + static_cast<size_t>(B) * P * 4, 256);
+    L.tau = off;   off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.cnt = off;   off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.cand = off;  off = align_up(off + static_cast<size_t>(B) * kCandCap * 8, 256);
+    L.flags = off; off = align_up(off + (static_cast<size_t>(B) + 4) * 4, 256);     // [0] = count, then row ids
+    L.fx = off;    off = align_up(off + static_cast<size_t>(kChunkRows) * D * 4, 256);
+    L.flat = off;  off = align_up(off + static_cast<size_t>(kChunkRows) * H * 4, 256);
+    L.fidx = off;  off = align_up(off + static_cast<size_t>(kChunkRows) * k * 4, 256);
+    L.fval = off;  off = align_up(off + static_cast<size_t>(kChunkRows) * k * 4, 256);
+    L.total = off;
+    return L;
+}
+
+// ---- sweep epilogue: threshold filter ---------------------------------------------------------
+template <int BM, int BN>
+struct EpiFilter {
+    static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
+    static constexpr int kCheckpoints = 0;
+    static constexpr int kLdsFloats = BN;      // per-row candidate counters
+    struct Args {
+        const float* bias;   // [hidden], already offset to the first swept hidden unit (may be null)
+        const float* tau;    // [B]
+        uint2* cand;         // [B][cap]
+        int* cnt;            // [B]  in: candidates already present, out: total
+        int cap;
+        int hidden_offset;   // index of the first swept hidden unit
+    };
+    float tau[NT];
+    bool col_ok[NT];
+
+    __device__ __forceinline__ void begin(const Args& a, const TileCtx& c) {
+        int* counters = reinterpret_cast<int*>(c.lds_epi);
+        if (c.tid < BN) {
+            const int row = c.n0 + c.tid;
+            counters[c.tid] = row < c.N ? a.cnt[row] : 0;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+            col_ok[nt] = col < c.N;
+            tau[nt] = col_ok[nt] ? a.tau[col] : __builtin_huge_valf();
+        }
+        // visibility of the counters: the kernel's first __syncthreads() follows begin()
+    }
+    __device__ __forceinline__ void init(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int h = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                h = h < c.M ? h : c.M - 1;
+                const float b = a.bias ? a.bias[h] : 0.0f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = b;
+            }
+    }
+    __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
+        int* counters = reinterpret_cast<int*>(c.lds_epi);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int lcol = c.wn * WTN + nt * 32 + c.lane_col;
+            const float t = tau[nt];
+            uint2* list = a.cand + static_cast<int64_t>(c.n0 + lcol) * a.cap;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mt][nt][r];
+                    if (!(v < t)) {      // v >= tau, or NaN (which ranks above everything)
+                        const int h = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                        if (h < c.M && col_ok[nt]) {
+                            const int pos = atomicAdd(&counters[lcol], 1);
+                            if (pos < a.cap)
+                                list[pos] = make_uint2(__float_as_uint(v), static_cast<uint32_t>(h + a.hidden_offset));
+                        }
+                    }
+                }
+        }
+    }
+    __device__ __forceinline__ void end(const Args& a, const TileCtx& c) {
+        __syncthreads();
+        const int* counters = reinterpret_cast<const int*>(c.lds_epi);
+        if (c.tid < BN) {
+            const int row = c.n0 + c.tid;
+            if (row < c.N) a.cnt[row] = counters[c.tid];
+        }
+    }
+};
+
+// ---- select: exact top-k of a row's candidates, one wave per row ---------------------------------
+constexpr int kSelWaves = 4;
+constexpr int kSelSlots = kCandCap / 64;   // candidates per lane
+
+__global__ void __launch_bounds__(64 * kSelWaves)
+select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, int B, int H, int k,
+                   int32_t* __restrict__ idx_out, float* __restrict__ val_out, int* __restrict__ flags) {
+    __shared__ unsigned long long sel[kSelWaves][256];
+    __shared__ unsigned short sel_src[kSelWaves][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * kSelWaves + wave;
+    if (b >= B) return;
+    const int n = cnt[b];
+    if (n < k || n > cap) {                       // tau not a lower bound, or list overflow
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+        return;
+    }
+    // 48-bit keys: (monotone value << 16) | (H-1-index); all distinct, larger = better
+    unsigned long long key[kSelSlots];
+    const uint2* list = cand + static_cast<int64_t>(b) * cap;
+#pragma unroll
+    for (int s = 0; s < kSelSlots; ++s) {
+        const int i = s * 64 + lane;
+        if (i < n) {
+            const uint2 c = list[i];
+            key[s] = (static_cast<unsigned long long>(mono_key(__uint_as_float(c.x))) << 16) |
+                     static_cast<unsigned long long>((H - 1) - static_cast<int>(c.y));
+        } else {
+            key[s] = 0ull;                        // below every real key (mono >= 0x007FFFFF)
+        }
+    }
+    const int nslots = (n + 63) / 64;             // wave-uniform
+    unsigned long long T = 0ull;
+    for (int bit = 47; bit >= 0; --bit) {
+        const unsigned long long trial = T | (1ull << bit);
+        int c = 0;
+        for (int s = 0; s < nslots; ++s) c += __popcll(__ballot(key[s] >= trial));
+        if (c >= k) T = trial;
+    }
+    // T is the k-th largest key: exactly k keys are >= T.  Compact them, then rank.
+    unsigned long long* mine = sel[wave];
+    unsigned short* src = sel_src[wave];
+    int base = 0;
+    for (int s = 0; s < nslots; ++s) {
+        const bool keep = key[s] >= T;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            mine[pos] = key[s];
+            src[pos] = static_cast<unsigned short>(s * 64 + lane);
+        }
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int j = lane; j < k; j += 64) {
+        const unsigned long long kj = mine[j];
+        int rank = 0;
+        for (int i = 0; i < k; ++i) rank += (mine[i] > kj) ? 1 : 0;
+        const uint2 c = list[src[j]];               // raw value bits and index of the survivor
+        idx_out[static_cast<int64_t>(b) * k + rank] = static_cast<int32_t>(c.y);
+        val_out[static_cast<int64_t>(b) * k + rank] = __uint_as_float(c.x);
+    }
+}
+
+// ---- fallback helpers ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, int n, int D, float* __restrict__ dst) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(n) * D) return;
+    const int r = static_cast<int>(gid / D), c = static_cast<int>(gid % D);
+    dst[gid] = src[static_cast<long long>(rows[r]) * D + c];
+}
+
+__global__ void __launch_bounds__(256)
+scatter_topk_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sval, const int* __restrict__ rows,
+                    int n, int k, int32_t* __restrict__ idx, float* __restrict__ val) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(n) * k) return;
+    const int r = static_cast<int>(gid / k), j = static_cast<int>(gid % k);
+    idx[static_cast<long long>(rows[r]) * k + j] = sidx[gid];
+    val[static_cast<long long>(rows[r]) * k + j] = sval[gid];
+}
+
+static int run_chunked(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
+                       float* val, float* lat, qsae_stream_t stream) {
+    for (int b0 = 0; b0 < B; b0 += kChunkRows) {
+        const int rows = (B - b0) < kChunkRows ? (B - b0) : kChunkRows;
+        int rc = qsae_encode_dense(x + static_cast<size_t>(b0) * D, W, bias, rows, D, H, QSAE_ACT_NONE, lat, H, stream);
+        if (rc != QSAE_OK) return rc;
+        rc = qsae_topk_rows(lat, H, rows, H, k, idx + static_cast<size_t>(b0) * k, val + static_cast<size_t>(b0) * k, 0,
+                            stream);
+        if (rc != QSAE_OK) return rc;
+    }
+    return QSAE_OK;
+}
+
+static int run_fused(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
+                     float* val, char* ws, qsae_stream_t stream) {
+    hipStream_t s = as_stream(stream);
+    const FusedLayout L = fused_layout(B, D, H, k);
+    const int P = pilot_width(H);
+    float* pilot = reinterpret_cast<float*>(ws + L.pilot);
+    float* tau = reinterpret_cast<float*>(ws + L.tau);
+    int* cnt = reinterpret_cast<int*>(ws + L.cnt);
+    uint2* cand = reinterpret_cast<uint2*>(ws + L.cand);
+    int* flags = reinterpret_cast<int*>(ws + L.flags);
+    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+    // 1. pilot block and per-row threshold
+    int rc = qsae_encode_dense(x, W, bias, B, D, P, QSAE_ACT_NONE, pilot, P, stream);
+    if (rc != QSAE_OK) return rc;
+    const int j = kPilotRank < P ? kPilotRank : P;
+    rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, s);
+    if (rc != QSAE_OK) return rc;
+    // 2. sweep of the remaining hidden units with the threshold filter (R = W rows, Cm = x rows)
+    {
+        constexpr int BM = 128, BN = 128, BK = 32;
+        using Epi = EpiFilter<BM, BN>;
+        typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P};
+        const int Hs = H - P;
+        if (D % BK == 0) {
+            using LA = LoaderF32<BM, BK, false>;
+            using LB = LoaderF32<BN, BK, false>;
+            typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
+            typename LB::Args lb{x, D, B};
+            rc = launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, Hs, B, D, /*sweep=*/0, s);
+        } else {
+            using LA = LoaderF32<BM, BK, true>;
+            using LB = LoaderF32<BN, BK, true>;
+            typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
+            typename LB::Args lb{x, D, B};
+            rc = launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, Hs, B, D, /*sweep=*/0, s);
+        }
+        if (rc != QSAE_OK) return rc;
+    }
+    // 3. exact selection among the candidates
+    hipLaunchKernelGGL(select_topk_kernel, dim3((B + kSelWaves - 1) / kSelWaves), dim3(64 * kSelWaves), 0, s, cand, cnt,
+                       kCandCap, B, H, k, idx, val, flags);
+    QSAE_LAUNCH_CHECK();
+    // 4. flagged rows (normally none): one 4-byte read-back, then the unfused kernels on those rows
+    int nflag = 0;
+    QSAE_HIP(hipMemcpyAsync(&nflag, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipStreamSynchronize(s));
+    if (nflag > 0) {
+        float* fx = reinterpret_cast<float*>(ws + L.fx);
+        float* flat = reinterpret_cast<float*>(ws + L.flat);
+        int32_t* fidx = reinterpret_cast<int32_t*>(ws + L.fidx);
+        float* fval = reinterpret_cast<float*>(ws + L.fval);
+        for (int f0 = 0; f0 < nflag; f0 += kChunkRows) {
+            const int n = (nflag - f0) < kChunkRows ? (nflag - f0) : kChunkRows;
+            const int* rows = flags + 1 + f0;
+            const long long tot = static_cast<long long>(n) * D;
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows,
+                               n, D, fx);
+            QSAE_LAUNCH_CHECK();
+            rc = qsae_encode_dense(fx, W, bias, n, D, H, QSAE_ACT_NONE, flat, H, stream);
+            if (rc != QSAE_OK) return rc;
+            rc = qsae_topk_rows(flat, H, n, H, k, fidx, fval, 0, stream);
+            if (rc != QSAE_OK) return rc;
+            const long long tk = static_cast<long long>(n) * k;
+            hipLaunchKernelGGL(scatter_topk_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx,
+                               fval, rows, n, k, idx, val);
+            QSAE_LAUNCH_CHECK();
+        }
+    }
+    return QSAE_OK;
+}
+
+}  // namespace qsae
 
 using namespace qsae;
 
+extern "C" int qsae_debug_set_topk_path(int path) {
+    g_force_path = path;
+    return QSAE_OK;
+}
+
 extern "C" size_t qsae_encode_topk_workspace_bytes(int B, int D, int H, int k) {
-    (void)D; (void)k;
-    if (B <= 0 || H <= 0) return 0;
+    if (B <= 0 || H <= 0 || D <= 0 || k <= 0) return 0;
+    if (use_fused(B, D, H, k)) return fused_layout(B, D, H, k).total;
     const size_t rows = static_cast<size_t>(B < kChunkRows ? B : kChunkRows);
     return rows * static_cast<size_t>(H) * sizeof(float);
 }
@@ -31,14 +345,10 @@ extern "C" int qsae_encode_topk(const float* x, const float* W, const float* bia
     if (workspace_bytes < qsae_encode_topk_workspace_bytes(B, D, H, k))
         return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", __func__);
     QSAE_CHECK_ARG(aligned16(workspace), "workspace must be 16-byte aligned");
-    float* lat = static_cast<float*>(workspace);
-    for (int b0 = 0; b0 < B; b0 += kChunkRows) {
-        const int rows = (B - b0) < kChunkRows ? (B - b0) : kChunkRows;
-        int rc = qsae_encode_dense(x + static_cast<size_t>(b0) * D, W, bias, rows, D, H, QSAE_ACT_NONE, lat, H, stream);
-        if (rc != QSAE_OK) return rc;
-        rc = qsae_topk_rows(lat, H, rows, H, k, idx + static_cast<size_t>(b0) * k, val + static_cast<size_t>(b0) * k, 0,
-                            stream);
-        if (rc != QSAE_OK) return rc;
+    if (use_fused(B, D, H, k)) {
+        QSAE_CHECK_SUPPORTED(D % 4 == 0, "D must be a multiple of 4");
+        QSAE_CHECK_ARG(aligned16(x) && aligned16(W), "x and W must be 16-byte aligned");
+        return run_fused(x, W, bias, B, D, H, k, idx, val, static_cast<char*>(workspace), stream);
     }
-    return QSAE_OK;
+    return run_chunked(x, W, bias, B, D, H, k, idx, val, static_cast<float*>(workspace), stream);
 }

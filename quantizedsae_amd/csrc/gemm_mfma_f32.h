@@ -67,17 +67,22 @@ struct LoaderF32 {
     };
     const float* rowp[PASSES];
     f32x4 r[PASSES];
+    Args args;
     int K, c, lrow;
 
-    __device__ __forceinline__ void init(const Args& a, int row0, int K_, int tid) {
+    __device__ __forceinline__ void init(const Args& a, int K_, int tid) {
+        args = a;
         K = K_;
         c = tid % G::CHUNKS;
         lrow = tid / G::CHUNKS;
+    }
+    // point the loader at the tile whose first row is row0
+    __device__ __forceinline__ void set_rows(int row0) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             int row = row0 + i * G::ROWS_PER_PASS + lrow;
-            row = row < a.nrows ? row : a.nrows - 1;
-            rowp[i] = a.p + static_cast<int64_t>(row) * a.ld + 4 * c;
+            row = row < args.nrows ? row : args.nrows - 1;
+            rowp[i] = args.p + static_cast<int64_t>(row) * args.ld + 4 * c;
         }
     }
     // KTAIL = false (K % BK == 0, the hot configuration): plain loads, nothing consumes them
@@ -118,17 +123,21 @@ struct LoaderCode2 {
     };
     const uint32_t* rowp[PASSES];
     uint32_t r[PASSES];
+    Args args;
     int K, c, lrow;
 
-    __device__ __forceinline__ void init(const Args& a, int row0, int K_, int tid) {
+    __device__ __forceinline__ void init(const Args& a, int K_, int tid) {
+        args = a;
         K = K_;
         c = tid % G::CHUNKS;
         lrow = tid / G::CHUNKS;
+    }
+    __device__ __forceinline__ void set_rows(int row0) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             int row = row0 + i * G::ROWS_PER_PASS + lrow;
-            row = row < a.nrows ? row : a.nrows - 1;
-            rowp[i] = a.p + static_cast<int64_t>(row) * a.words_ld;
+            row = row < args.nrows ? row : args.nrows - 1;
+            rowp[i] = args.p + static_cast<int64_t>(row) * args.words_ld;
         }
     }
     __device__ __forceinline__ void load(int kt) {
@@ -177,18 +186,22 @@ struct LoaderBitsScale {
     uint32_t r[PASSES];
     f32x4 s;
     const float* scale;
+    Args args;
     int K, c, lrow;
 
-    __device__ __forceinline__ void init(const Args& a, int row0, int K_, int tid) {
+    __device__ __forceinline__ void init(const Args& a, int K_, int tid) {
+        args = a;
         K = K_;
         c = tid % G::CHUNKS;
         lrow = tid / G::CHUNKS;
         scale = a.scale;
+    }
+    __device__ __forceinline__ void set_rows(int row0) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             int row = row0 + i * G::ROWS_PER_PASS + lrow;
-            row = row < a.nrows ? row : a.nrows - 1;
-            rowp[i] = a.bits + static_cast<int64_t>(row) * a.words_ld;
+            row = row < args.nrows ? row : args.nrows - 1;
+            rowp[i] = args.bits + static_cast<int64_t>(row) * args.words_ld;
         }
     }
     __device__ __forceinline__ void load(int kt) {
@@ -225,32 +238,36 @@ struct LoaderBitsScale {
 };
 
 // -------------------------------------------------------------------------------------
-// Workgroup -> tile mapping.  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the
-// blocks that share an L2); give each XCD a contiguous run of tiles walked in groups of
-// GROUP_M row-tiles so that the ~32 tiles in flight on one XCD share 8 R-panels and 4
-// Cm-panels in its L2.  Bijective for any tile count.  Speed only, never correctness.
-struct TileMap {
-    int tiles_m, tiles_n;
-    __device__ __forceinline__ void locate(int bid, int nblocks, int& tm, int& tn) const {
-        constexpr int NXCD = 8, GROUP_M = 8;
+// Workgroup -> work mapping.  A workgroup owns ONE Cm panel (BN rows of the K-contiguous
+// "column" operand) and sweeps `sweep` consecutive R tiles (BM rows each) against it, keeping
+// the global->LDS pipeline running across tile boundaries (no per-tile prologue).  The
+// encoder+top-k path sets sweep = all R tiles so that a workgroup sees whole latent rows.
+// Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the blocks that share an L2): each
+// XCD gets a contiguous run of work items, ordered so that the blocks resident together on one
+// XCD share Cm panels.  Bijective for any block count.  Speed only, never correctness.
+struct SweepMap {
+    int tiles_m, tiles_n, sweep, msplit;    // msplit = ceil(tiles_m / sweep)
+    __device__ __forceinline__ void locate(int bid, int nblocks, int& tn, int& m_first, int& m_last) const {
+        constexpr int NXCD = 8;
         const int q = nblocks / NXCD, rem = nblocks % NXCD;
         const int xcd = bid % NXCD, slot = bid / NXCD;
         const int vid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + slot;
-        const int per_group = GROUP_M * tiles_n;
-        const int group = vid / per_group, in_group = vid % per_group;
-        const int first_m = group * GROUP_M;
-        const int gsize = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-        tm = first_m + in_group % gsize;
-        tn = in_group / gsize;
+        tn = vid / msplit;
+        const int ms = vid % msplit;
+        m_first = ms * sweep;
+        m_last = (m_first + sweep) < tiles_m ? (m_first + sweep) : tiles_m;
     }
 };
 
 // -------------------------------------------------------------------------------------
 // The kernel.  Epi provides:
-//   struct Args;
-//   static constexpr int kCheckpoints (0 = single epilogue at the end)
-//   __device__ void init(acc, ctx)            -- accumulator seed (bias)
-//   __device__ void finish(acc, ctx)          -- consume the finished tile
+//   struct Args;  static constexpr int kCheckpoints;
+//   __device__ void begin(args, ctx, smem_epi)   -- once per workgroup, before the sweep
+//   __device__ void init(args, acc, ctx)         -- accumulator seed for the tile at ctx.m0
+//   __device__ void checkpoint(args, acc, ctx, k_done)   (only if kCheckpoints)
+//   __device__ void finish(args, acc, ctx)       -- consume the finished tile
+//   __device__ void end(args, ctx)               -- once per workgroup, after the sweep
+//   static constexpr int kLdsFloats               -- extra LDS the epilogue wants
 // ctx carries tile origin, wave/lane coordinates and problem sizes.
 struct TileCtx {
     int m0, n0;        // tile origin (row of R, row of Cm)
@@ -259,6 +276,7 @@ struct TileCtx {
     int lane_half;     // lane >> 5  -> +4 on the output row
     int M, N, K;
     int tid;
+    float* lds_epi;    // epilogue scratch (kLdsFloats floats), after the staging buffers
 };
 
 // Output row inside a 32x32 MFMA tile held by accumulator register `reg` of this lane.
@@ -266,36 +284,40 @@ __device__ __forceinline__ int mfma_row(int reg, int lane_half) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * lane_half;
 }
 
+// 128x128 tiles are sized for two workgroups per CU (LDS 2 x 74 KB, <= 256 registers per lane):
+// the second launch-bounds argument (waves per SIMD) makes the register allocator honour that.
 template <class LA, class LB, class Epi, int BM, int BN, int BK>
-__global__ void __launch_bounds__(kGemmThreads)
+__global__ void __launch_bounds__(kGemmThreads, (BM * BN <= 128 * 128) ? 2 : 1)
 gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Args ea, int M, int N,
-                   int K, TileMap map) {
+                   int K, SweepMap map) {
     using G = TileGeom<BK>;
     constexpr int WTM = BM / 2, WTN = BN / 2;      // per-wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;    // MFMA tiles per wave
     constexpr int TILE_A = BM * G::LDS_STRIDE, TILE_B = BN * G::LDS_STRIDE;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][TILE_A + TILE_B]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][TILE_A + TILE_B] + epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     TileCtx ctx;
-    int tm, tn;
-    map.locate(blockIdx.x, gridDim.x, tm, tn);
-    ctx.m0 = tm * BM;
+    int tn, m_first, m_last;
+    map.locate(blockIdx.x, gridDim.x, tn, m_first, m_last);
     ctx.n0 = tn * BN;
     ctx.wm = wave >> 1;
     ctx.wn = wave & 1;
     ctx.lane_col = lane & 31;
     ctx.lane_half = lane >> 5;
     ctx.M = M; ctx.N = N; ctx.K = K; ctx.tid = tid;
+    ctx.lds_epi = smem + 2 * (TILE_A + TILE_B);
+    ctx.m0 = m_first * BM;
 
     LA a;
     LB b;
-    a.init(la, ctx.m0, K, tid);
-    b.init(lb, ctx.n0, K, tid);
+    a.init(la, K, tid);
+    b.init(lb, K, tid);
+    a.set_rows(ctx.m0);
+    b.set_rows(ctx.n0);
 
-    f32x16 acc[MT][NT];
     Epi epi;
-    epi.init(ea, acc, ctx);
+    epi.begin(ea, ctx);
 
     const int nk = (K + BK - 1) / BK;
     a.load(0);
@@ -306,66 +328,93 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
 
     const int arow = (ctx.wm * WTM + ctx.lane_col) * G::LDS_STRIDE + 4 * ctx.lane_half;
     const int brow = (ctx.wn * WTN + ctx.lane_col) * G::LDS_STRIDE + 4 * ctx.lane_half;
+    int buf = 0;
 
 #pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* sA = smem + (kt & 1) * (TILE_A + TILE_B);
-        const float* sB = sA + TILE_A;
-        float* nA = smem + ((kt + 1) & 1) * (TILE_A + TILE_B);
-        const bool more = (kt + 1) < nk;
-        if (more) {
-            a.load(kt + 1);
-            b.load(kt + 1);
-        }
+    for (int tile = m_first; tile < m_last; ++tile) {
+        ctx.m0 = tile * BM;
+        f32x16 acc[MT][NT];
+        epi.init(ea, acc, ctx);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* sA = smem + buf * (TILE_A + TILE_B);
+            const float* sB = sA + TILE_A;
+            float* nA = smem + (buf ^ 1) * (TILE_A + TILE_B);
+            const bool last_k = (kt + 1) == nk;
+            const bool more = !last_k || (tile + 1) < m_last;
+            if (more) {
+                // next slice of this tile, or the first slice of the next tile of the sweep
+                if (last_k) a.set_rows((tile + 1) * BM);
+                a.load(last_k ? 0 : kt + 1);
+                b.load(last_k ? 0 : kt + 1);
+            }
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[MT], bf[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                af[mt] = *reinterpret_cast<const f32x4*>(sA + arow + mt * 32 * G::LDS_STRIDE + 8 * g);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                bf[nt] = *reinterpret_cast<const f32x4*>(sB + brow + nt * 32 * G::LDS_STRIDE + 8 * g);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 af[MT], bf[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
+                    af[mt] = *reinterpret_cast<const f32x4*>(sA + arow + mt * 32 * G::LDS_STRIDE + 8 * g);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t],
-                                                                           acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    bf[nt] = *reinterpret_cast<const f32x4*>(sB + brow + nt * 32 * G::LDS_STRIDE + 8 * g);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t],
+                                                                               acc[mt][nt], 0, 0, 0);
+            }
+            if (Epi::kCheckpoints) epi.checkpoint(ea, acc, ctx, (kt + 1) * BK);
+            if (more) {
+                a.store(nA);
+                b.store(nA + TILE_A);
+            }
+            __syncthreads();
+            buf ^= 1;
         }
-        if (Epi::kCheckpoints) epi.checkpoint(ea, acc, ctx, (kt + 1) * BK);
-        if (more) {
-            a.store(nA);
-            b.store(nA + TILE_A);
-        }
-        __syncthreads();
+        epi.finish(ea, acc, ctx);
     }
-    epi.finish(ea, acc, ctx, smem);
+    epi.end(ea, ctx);
+}
+
+// Sweep length heuristic for kernels without row ownership: long enough to amortise the pipeline
+// fill, short enough to leave >= ~2048 workgroups for load balance.  g_sweep_override > 0 forces it.
+extern int g_sweep_override;
+template <int BM, int BN>
+inline int pick_sweep(int M, int N, int /*K*/) {
+    if (g_sweep_override > 0) return g_sweep_override;
+    const long long tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    long long s = tiles_m * tiles_n / 2048;
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    return static_cast<int>(s);
 }
 
 template <int BM, int BN, int BK>
-constexpr size_t gemm_lds_bytes() {
-    return 2ull * (BM + BN) * (BK + 4) * sizeof(float);
+constexpr size_t gemm_lds_bytes(int epi_floats) {
+    return (2ull * (BM + BN) * (BK + 4) + static_cast<size_t>(epi_floats)) * sizeof(float);
 }
 
-// Host-side launcher.
+// Host-side launcher.  sweep = number of consecutive R tiles per workgroup (<= 0: all of them).
 template <class LA, class LB, class Epi, int BM, int BN, int BK>
 inline int launch_gemm(const typename LA::Args& la, const typename LB::Args& lb,
-                       const typename Epi::Args& ea, int M, int N, int K, hipStream_t stream) {
+                       const typename Epi::Args& ea, int M, int N, int K, int sweep, hipStream_t stream) {
     auto kern = gemm_nt_f32_kernel<LA, LB, Epi, BM, BN, BK>;
-    constexpr size_t lds = gemm_lds_bytes<BM, BN, BK>();
+    constexpr size_t lds = gemm_lds_bytes<BM, BN, BK>(Epi::kLdsFloats);
     static bool configured = false;   // per instantiation
     if (!configured) {
         QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         configured = true;
     }
-    TileMap map;
+    SweepMap map;
     map.tiles_m = (M + BM - 1) / BM;
     map.tiles_n = (N + BN - 1) / BN;
-    const long long nblocks = static_cast<long long>(map.tiles_m) * map.tiles_n;
+    map.sweep = (sweep <= 0 || sweep > map.tiles_m) ? map.tiles_m : sweep;
+    map.msplit = (map.tiles_m + map.sweep - 1) / map.sweep;
+    const long long nblocks = static_cast<long long>(map.tiles_n) * map.msplit;
     if (nblocks <= 0 || nblocks > 0x7FFFFFFFll) return fail(QSAE_ERR_UNSUPPORTED, "%s: tile count out of range", __func__);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kGemmThreads), lds, stream, la, lb,
                        ea, M, N, K, map);

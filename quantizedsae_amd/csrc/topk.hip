@@ -36,10 +36,20 @@ __device__ __forceinline__ unsigned long long key48(float v, uint32_t idx) {
     return (static_cast<unsigned long long>(mono_key(v)) << 16) | (0xFFFFu - (idx & 0xFFFFu));
 }
 
+// Pilot mode (tau_out != nullptr): instead of idx/val the kernel emits, per row, tau = the k-th
+// largest value and appends EVERY element >= tau (ties included) as (value bits, index) pairs to
+// cand[row][0..cap) with their count in cnt[row] -- the seed of the fused encoder+top-k filter.
+struct PilotOut {
+    float* tau;
+    uint2* cand;
+    int* cnt;
+    int cap;
+};
+
 template <int VPT4>
 __global__ void __launch_bounds__(kTopkThreads)
 topk_rows_kernel(float* __restrict__ latent, int64_t ld, int H, int k, int32_t* __restrict__ idx_out,
-                 float* __restrict__ val_out, int zero_rest) {
+                 float* __restrict__ val_out, int zero_rest, PilotOut pilot) {
     __shared__ TopkShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* row = latent + static_cast<int64_t>(blockIdx.x) * ld;
@@ -157,15 +167,42 @@ topk_rows_kernel(float* __restrict__ latent, int64_t ld, int H, int k, int32_t* 
         for (int j = 0; j < n; ++j) rank += (sh.cand[j] > mine) ? 1 : 0;
         if (rank < k) {
             const uint32_t e = key_index(mine);
-            // recover the value from the register-resident row copy is awkward; re-read it
-            const float x = row[e];
-            idx_out[static_cast<int64_t>(blockIdx.x) * k + rank] = static_cast<int32_t>(e);
-            val_out[static_cast<int64_t>(blockIdx.x) * k + rank] = x;
+            if (idx_out) {
+                // recovering the value from the register-resident row copy is awkward; re-read it
+                const float x = row[e];
+                idx_out[static_cast<int64_t>(blockIdx.x) * k + rank] = static_cast<int32_t>(e);
+                val_out[static_cast<int64_t>(blockIdx.x) * k + rank] = x;
+            }
             if (rank == k - 1) sh.kth = mine;
         }
     }
-    if (!zero_rest) return;
+    if (!zero_rest && pilot.tau == nullptr) return;
     __syncthreads();
+
+    if (pilot.tau != nullptr) {
+        const uint32_t km = static_cast<uint32_t>(sh.kth >> 32);
+        const uint32_t kb = (km & 0x80000000u) ? (km & 0x7FFFFFFFu) : ~km;
+        // a NaN k-th value gives tau = +inf: only NaNs (and +inf) pass !(x < tau)
+        const float tf = (km == 0xFFFFFFFFu) ? __builtin_huge_valf() : __uint_as_float(kb);
+        if (tid == 0) { pilot.tau[blockIdx.x] = tf; sh.count = 0; }
+        __syncthreads();
+        uint2* list = pilot.cand + static_cast<int64_t>(blockIdx.x) * pilot.cap;
+#pragma unroll
+        for (int i = 0; i < VPT4; ++i) {
+            const int e = (i * kTopkThreads + tid) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = v[i][j];
+                if ((e + j) < H && !(x < tf)) {
+                    const int pos = atomicAdd(&sh.count, 1);
+                    if (pos < pilot.cap) list[pos] = make_uint2(__float_as_uint(x), static_cast<uint32_t>(e + j));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) pilot.cnt[blockIdx.x] = sh.count;
+        return;
+    }
 
     // ---- 5. rewrite the row: keep keys >= kth, zero the rest ----------------------------
     const unsigned long long kth = sh.kth;
@@ -190,11 +227,24 @@ topk_rows_kernel(float* __restrict__ latent, int64_t ld, int H, int k, int32_t* 
 
 template <int VPT4>
 static int launch_topk(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
-                       hipStream_t s) {
+                       const PilotOut& pilot, hipStream_t s) {
     hipLaunchKernelGGL(topk_rows_kernel<VPT4>, dim3(B), dim3(kTopkThreads), 0, s, latent, ld, H, k, idx, val,
-                       zero_rest);
+                       zero_rest, pilot);
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
+}
+
+// shared by qsae_topk_rows and the pilot stage of qsae_encode_topk (encode_topk.hip)
+int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
+                       float* tau, uint2* cand, int* cnt, int cap, hipStream_t s) {
+    const PilotOut pilot{tau, cand, cnt, cap};
+    const int per_thread4 = (H + 1023) / 1024;
+    if (per_thread4 <= 1) return launch_topk<1>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
+    if (per_thread4 <= 2) return launch_topk<2>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
+    if (per_thread4 <= 4) return launch_topk<4>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
+    if (per_thread4 <= 8) return launch_topk<8>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
+    if (per_thread4 <= 16) return launch_topk<16>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
+    return launch_topk<32>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
 }
 
 }  // namespace qsae
@@ -212,12 +262,6 @@ extern "C" int qsae_topk_rows(float* latent, int64_t ld, int B, int H, int k, in
     QSAE_CHECK_SUPPORTED(H <= 32768, "H <= 32768");
     QSAE_CHECK_SUPPORTED(H % 4 == 0 && ld % 4 == 0, "H and ld must be multiples of 4");
     QSAE_CHECK_ARG(aligned16(latent), "latent must be 16-byte aligned");
-    hipStream_t s = as_stream(stream);
-    const int per_thread4 = (H + 1023) / 1024;
-    if (per_thread4 <= 1) return launch_topk<1>(latent, ld, B, H, k, idx, val, zero_rest, s);
-    if (per_thread4 <= 2) return launch_topk<2>(latent, ld, B, H, k, idx, val, zero_rest, s);
-    if (per_thread4 <= 4) return launch_topk<4>(latent, ld, B, H, k, idx, val, zero_rest, s);
-    if (per_thread4 <= 8) return launch_topk<8>(latent, ld, B, H, k, idx, val, zero_rest, s);
-    if (per_thread4 <= 16) return launch_topk<16>(latent, ld, B, H, k, idx, val, zero_rest, s);
-    return launch_topk<32>(latent, ld, B, H, k, idx, val, zero_rest, s);
+    return topk_rows_dispatch(latent, ld, B, H, k, idx, val, zero_rest, nullptr, nullptr, nullptr, 0,
+                              as_stream(stream));
 }

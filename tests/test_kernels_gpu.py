@@ -295,3 +295,53 @@ def test_error_codes():
         ops.topk_rows(torch.zeros((2, 64), device=DEV), 65, True)   # k > H
     with pytest.raises(RuntimeError):
         ops.encode_dense(torch.zeros((4, 8)), torch.zeros((8, 8)), None)   # CPU tensors: no fallback
+
+
+# ---- fused encoder + top-k (pilot threshold, sweep filter, select, fallback) -----------------------
+def set_topk_path(path):
+    from quantizedsae_amd import _lib
+    lib = _lib.load()
+    lib.qsae_debug_set_topk_path.argtypes = [C.c_int]
+    lib.qsae_debug_set_topk_path(path)
+
+
+@pytest.fixture()
+def fused_path():
+    set_topk_path(2)
+    yield
+    set_topk_path(0)
+
+
+@pytest.mark.parametrize("B,D,H,k", [(300, 64, 4096, 8), (1000, 512, 8192, 65), (129, 48, 4100, 3), (2100, 512, 32768, 65)])
+def test_encode_topk_fused_equals_oracle(fused_path, B, D, H, k):
+    ops = _ops()
+    x = S.activations(80, B, D)
+    W = S.xavier_uniform(80, H, D, stream=1)
+    bias = S.normal(80, (H,), stream=3, std=0.05)
+    idx, val = ops.encode_topk(dev(x), dev(W), dev(bias), k)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    idx2, val2 = ops.encode_topk(dev(x), dev(W), None, k)
+    w2 = oracle.topk(oracle.encode(x, W, None), k)
+    assert np.array_equal(host(idx2), w2[0]) and np.array_equal(host(val2), w2[1])
+
+
+def test_encode_topk_fused_fallback_rows(fused_path):
+    """Rows the pilot threshold cannot serve: (a) all-equal latents -> every hidden unit ties, the
+    candidate list overflows; (b) the whole top-k inside the pilot block -> fewer than k candidates;
+    both must come back exact through the flagged-row fallback, next to ordinary rows."""
+    ops = _ops()
+    B, D, H, k = 260, 64, 4096, 40
+    x = S.activations(81, B, D)
+    W = S.xavier_uniform(81, H, D, stream=1)
+    bias = np.zeros((H,), np.float32)
+    x[3] = 0.0                                    # (a) latent row == bias == 0 everywhere
+    x[200] = 0.0
+    bias2 = bias.copy()
+    bias2[:100] = 50.0                            # (b) top-40 of EVERY row sits in the first 100 hidden units
+    for b_ in (bias, bias2):
+        idx, val = ops.encode_topk(dev(x), dev(W), dev(b_), k)
+        want_idx, want_val = oracle.topk(oracle.encode(x, W, b_), k)
+        assert np.array_equal(host(idx), want_idx)
+        assert np.array_equal(host(val), want_val)
