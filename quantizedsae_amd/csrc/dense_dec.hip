@@ -278,8 +278,6 @@ extern "C" int qsae_decode_ternary_dense(const float* h, int64_t ld, int B, int 
     QSAE_CHECK_SUPPORTED(H % 4 == 0 && ld % 4 == 0, "H and ld must be multiples of 4");
     QSAE_CHECK_ARG(aligned16(h), "h must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    const long long t256 = static_cast<long long>((B + 255) / 256) * ((D + 255) / 256);
-    if (t256 >= 256) return run_ternary<256, 256, 32>(h, ld, B, H, codes2, D, recon, s);
     return run_ternary<128, 128, 32>(h, ld, B, H, codes2, D, recon, s);
 }
 
@@ -340,11 +338,6 @@ extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, i
         hipLaunchKernelGGL(count_bits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, zbits, words_ld, B,
                            words, lv, l0_counts);
         QSAE_LAUNCH_CHECK();
-    }
-    const long long t256 = static_cast<long long>((B + 255) / 256) * ((D + 255) / 256);
-    if (t256 >= 256) {
-        typename EpiLevels<256, 256>::Args ea{lv, allow_bias ? bias : nullptr, levels, static_cast<int64_t>(B) * D};
-        return run_matryoshka<256, 256, 32>(zbits, words_ld, B, H, D, codes2t, scale, ea, s);
     }
     typename EpiLevels<128, 128>::Args ea{lv, allow_bias ? bias : nullptr, levels, static_cast<int64_t>(B) * D};
     return run_matryoshka<128, 128, 32>(zbits, words_ld, B, H, D, codes2t, scale, ea, s);

@@ -10,7 +10,7 @@
 
 namespace qsae {
 
-static int g_gemm_config = 0;   // 0 = auto, 1 = 256x256x32, 2 = 128x128x32, 3 = 256x256x16
+static int g_gemm_config = 0;   // kept for the debug ABI; only one tile shape is built
 int g_sweep_override = 0;       // 0 = heuristic (pick_sweep)
 
 // ---- epilogues ------------------------------------------------------------------------
@@ -110,8 +110,9 @@ template <class Epi, int BM, int BN, int BK>
 static int run_encoder(const float* x, const float* W, int B, int D, int H, const typename Epi::Args& ea,
                        hipStream_t s) {
     if (D % BK == 0) {
-        using LA = LoaderF32<BM, BK, false>;
-        using LB = LoaderF32<BN, BK, false>;
+        constexpr bool kAsm = (BM == 128 && BN == 128);     // audited spill-free instantiations only
+        using LA = LoaderF32<BM, BK, false, kAsm>;
+        using LB = LoaderF32<BN, BK, false, kAsm>;
         typename LA::Args la{x, D, B};
         typename LB::Args lb{W, D, H};
         return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, H, D, pick_sweep<BM, BN>(B, H, D), s);
@@ -139,22 +140,14 @@ static int run_bits(const float* x, const float* W, const float* bias, int B, in
     return run_encoder<Epi, BM, BN, BK>(x, W, B, D, H, ea, s);
 }
 
-// Tile choice: 256x256 tiles halve the L2->LDS traffic per FLOP; use them once they fill the
-// chip (>= 256 tiles), otherwise 128x128 for more workgroups.
-static int pick_config(int M, int N) {
-    if (g_gemm_config) return g_gemm_config;
-    (void)M; (void)N;
-    return 2;   // 128x128x32 at two workgroups per CU measured fastest (profiles/r01_*)
-}
+// One tile shape: 128 x 128 x 32, two workgroups per CU (LDS 2 x 74 KB, <= 256 registers per lane).
+// 256 x 256 tiles (one wave per SIMD) were measured slower and, with the two-deep staging sets, no
+// longer fit the register file (profiles/r01_*; DESIGN.md "what was tried").
 
 template <int ACT>
 static int dispatch_dense(const float* x, const float* W, const float* bias, int B, int D, int H, float* out,
                           int64_t ld, hipStream_t s) {
-    switch (pick_config(B, H)) {
-        case 1: return run_dense<ACT, 256, 256, 32>(x, W, bias, B, D, H, out, ld, s);
-        case 3: return run_dense<ACT, 256, 256, 16>(x, W, bias, B, D, H, out, ld, s);
-        default: return run_dense<ACT, 128, 128, 32>(x, W, bias, B, D, H, out, ld, s);
-    }
+    return run_dense<ACT, 128, 128, 32>(x, W, bias, B, D, H, out, ld, s);
 }
 
 }  // namespace qsae
@@ -164,6 +157,28 @@ using namespace qsae;
 extern "C" int qsae_debug_set_gemm_config(int cfg) {
     g_gemm_config = cfg;
     return QSAE_OK;
+}
+
+// Diagnosis only: the encoder contraction with parts of the pipeline removed (results are wrong).
+extern "C" int qsae_debug_encode_ablate(const float* x, const float* W, int B, int D, int H, float* out, int cfg,
+                                        int ablate, qsae_stream_t stream) {
+    hipStream_t s = as_stream(stream);
+#define QSAE_ABL(BM, BN, BK, AB)                                                                   \
+    {                                                                                              \
+        /* asm-staged loads only in the complete pipeline: an ablated build never waits for them */ \
+        using LA = LoaderF32<BM, BK, false, (AB == 0)>;                                            \
+        using LB = LoaderF32<BN, BK, false, (AB == 0)>;                                            \
+        using Epi = EpiDense<QSAE_ACT_NONE, BM, BN>;                                               \
+        typename LA::Args la{x, D, B};                                                             \
+        typename LB::Args lb{W, D, H};                                                             \
+        typename Epi::Args ea{nullptr, out, H};                                                    \
+        return launch_gemm<LA, LB, Epi, BM, BN, BK, AB>(la, lb, ea, B, H, D, pick_sweep<BM, BN>(B, H, D), s); \
+    }
+    (void)cfg;
+    if (ablate == 1) QSAE_ABL(128, 128, 32, 1)
+    if (ablate == 2) QSAE_ABL(128, 128, 32, 2)
+    QSAE_ABL(128, 128, 32, 0)
+#undef QSAE_ABL
 }
 
 extern "C" int qsae_debug_set_sweep(int sweep) {
@@ -202,9 +217,5 @@ extern "C" int qsae_encode_bits(const float* x, const float* W, const float* bia
     const int64_t used = (H + 31) / 32;
     if (words_ld > used)
         QSAE_HIP(hipMemset2DAsync(zbits + used, words_ld * 4, 0, (words_ld - used) * 4, B, s));
-    switch (pick_config(B, H)) {
-        case 1: return run_bits<256, 256, 32>(x, W, bias, B, D, H, zbits, words_ld, s);
-        case 3: return run_bits<256, 256, 16>(x, W, bias, B, D, H, zbits, words_ld, s);
-        default: return run_bits<128, 128, 32>(x, W, bias, B, D, H, zbits, words_ld, s);
-    }
+    return run_bits<128, 128, 32>(x, W, bias, B, D, H, zbits, words_ld, s);
 }

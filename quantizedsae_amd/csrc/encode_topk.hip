@@ -34,6 +34,11 @@ constexpr int kFusedMinRows = 2048;
 constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 
+// Optional HIP-event bracket around the sweep kernel (bench.py's live roofline measurement): events
+// are recorded on the launch stream and only read by qsae_debug_sweep_timing_collect().
+static bool g_time_sweep = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_sweep_events;
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static bool use_fused(int B, int D, int H, int k) {
@@ -271,9 +276,15 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
         using Epi = EpiFilter<BM, BN>;
         typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P};
         const int Hs = H - P;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_time_sweep) {
+            QSAE_HIP(hipEventCreate(&e0));
+            QSAE_HIP(hipEventCreate(&e1));
+            QSAE_HIP(hipEventRecord(e0, s));
+        }
         if (D % BK == 0) {
-            using LA = LoaderF32<BM, BK, false>;
-            using LB = LoaderF32<BN, BK, false>;
+            using LA = LoaderF32<BM, BK, false, true>;
+            using LB = LoaderF32<BN, BK, false, true>;
             typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
             typename LB::Args lb{x, D, B};
             rc = launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, Hs, B, D, /*sweep=*/0, s);
@@ -283,6 +294,10 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
             typename LB::Args lb{x, D, B};
             rc = launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, Hs, B, D, /*sweep=*/0, s);
+        }
+        if (g_time_sweep) {
+            QSAE_HIP(hipEventRecord(e1, s));
+            g_sweep_events.emplace_back(e0, e1);
         }
         if (rc != QSAE_OK) return rc;
     }
@@ -322,6 +337,32 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
 }  // namespace qsae
 
 using namespace qsae;
+
+extern "C" int qsae_debug_sweep_timing(int enable) {
+    g_time_sweep = enable != 0;
+    return QSAE_OK;
+}
+
+// Sum of the sweep-kernel durations recorded since the last collect (caller has synchronised).
+extern "C" int qsae_debug_sweep_timing_collect(double* total_ms, int* launches) {
+    double tot = 0.0;
+    int n = 0;
+    for (auto& ev : g_sweep_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; ++n; }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    g_sweep_events.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return QSAE_OK;
+}
+
+// fraction of the encoder FLOPs the sweep launch covers (the pilot block takes the rest)
+extern "C" double qsae_debug_sweep_flop_fraction(int H) {
+    return static_cast<double>(H - pilot_width(H)) / static_cast<double>(H);
+}
 
 extern "C" int qsae_debug_set_topk_path(int path) {
     g_force_path = path;

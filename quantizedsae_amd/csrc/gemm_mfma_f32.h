@@ -23,6 +23,8 @@
 // bank-conflict free (bank = dword address mod 64 / mod 32).
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace qsae {
@@ -55,7 +57,7 @@ __device__ __forceinline__ void lds_store_chunk(float* row, int c, f32x4 v) {
 
 // fp32 rows [nrows][ld], rows >= nrows are clamped (their outputs are never stored),
 // columns >= K read as zero (fma(0,0,acc) == acc keeps the chain exact).
-template <int ROWS, int BK, bool KTAIL = false>
+template <int ROWS, int BK, bool KTAIL = false, bool ASM = false>
 struct LoaderF32 {
     using G = TileGeom<BK>;
     static constexpr int PASSES = ROWS / G::ROWS_PER_PASS;
@@ -65,8 +67,15 @@ struct LoaderF32 {
         int64_t ld;
         int nrows;
     };
+    // The hot (K % BK == 0) variant issues its loads from inline asm: hipcc cannot tell the two
+    // staging sets apart across loop iterations and would drain the newer set with vmcnt(0);
+    // the kernel waits for them itself with a counted s_waitcnt (wait_staged below).
+    // Opt-in (ASM) and only for register-lean tiles: an asm load's destination must never be spilled
+    // or copied before the wait (cdna guide 5.7 item 1), which is audited per instantiation.
+    static constexpr bool kAsmLoads = ASM && !KTAIL;
+    static constexpr int kLoadsPerStep = PASSES;
     const float* rowp[PASSES];
-    f32x4 r[PASSES];
+    f32x4 r[2][PASSES];      // two staging sets: slices are fetched two steps ahead
     Args args;
     int K, c, lrow;
 
@@ -88,6 +97,7 @@ struct LoaderF32 {
     // KTAIL = false (K % BK == 0, the hot configuration): plain loads, nothing consumes them
     // until store(), so their latency hides under the MFMAs of the current slice.
     // KTAIL = true: chunks at or beyond K re-read the row start and are zeroed.
+    template <int P>
     __device__ __forceinline__ void load(int kt) {
         const int k0 = kt * BK;
         if (KTAIL) {
@@ -96,17 +106,32 @@ struct LoaderF32 {
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(rowp[i] + koff);
-                r[i] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+                r[P][i] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else if (ASM) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) {
+                const float* p = rowp[i] + k0;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[P][i]) : "v"(p) : "memory");
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < PASSES; ++i) r[i] = *reinterpret_cast<const f32x4*>(rowp[i] + k0);
+            for (int i = 0; i < PASSES; ++i) r[P][i] = *reinterpret_cast<const f32x4*>(rowp[i] + k0);
         }
     }
+    // order every register of set P behind the caller's s_waitcnt (cdna guide 5.7, form ii)
+    template <int P>
+    __device__ __forceinline__ void pin() {
+        if (kAsmLoads) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i) asm volatile("" : "+v"(r[P][i]));
+        }
+    }
+    template <int P>
     __device__ __forceinline__ void store(float* tile) const {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i)
-            lds_store_chunk(tile + (i * G::ROWS_PER_PASS + lrow) * G::LDS_STRIDE, c, r[i]);
+            lds_store_chunk(tile + (i * G::ROWS_PER_PASS + lrow) * G::LDS_STRIDE, c, r[P][i]);
     }
 };
 
@@ -121,8 +146,11 @@ struct LoaderCode2 {
         int64_t words_ld;
         int nrows;
     };
+    static constexpr bool kAsmLoads = false;
+    static constexpr int kLoadsPerStep = PASSES;
+    template <int P> __device__ __forceinline__ void pin() {}
     const uint32_t* rowp[PASSES];
-    uint32_t r[PASSES];
+    uint32_t r[2][PASSES];
     Args args;
     int K, c, lrow;
 
@@ -140,6 +168,7 @@ struct LoaderCode2 {
             rowp[i] = args.p + static_cast<int64_t>(row) * args.words_ld;
         }
     }
+    template <int P>
     __device__ __forceinline__ void load(int kt) {
         const int k = kt * BK + 4 * c;            // first field of this thread's chunk
         if (KTAIL) {
@@ -148,18 +177,19 @@ struct LoaderCode2 {
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const uint32_t t = rowp[i][w];
-                r[i] = ok ? t : 0u;
+                r[P][i] = ok ? t : 0u;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < PASSES; ++i) r[i] = rowp[i][k >> 4];
+            for (int i = 0; i < PASSES; ++i) r[P][i] = rowp[i][k >> 4];
         }
     }
+    template <int P>
     __device__ __forceinline__ void store(float* tile) const {
         const int sh = 2 * ((4 * c) & 15);
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            const int w = static_cast<int>(r[i] >> sh);
+            const int w = static_cast<int>(r[P][i] >> sh);
             f32x4 v;
             v[0] = static_cast<float>(MUL * sbfe_i32(w, 0, 2));
             v[1] = static_cast<float>(MUL * sbfe_i32(w, 2, 2));
@@ -182,9 +212,12 @@ struct LoaderBitsScale {
         int nrows;
         const float* scale;
     };
+    static constexpr bool kAsmLoads = false;
+    static constexpr int kLoadsPerStep = PASSES + 1;
+    template <int P> __device__ __forceinline__ void pin() {}
     const uint32_t* rowp[PASSES];
-    uint32_t r[PASSES];
-    f32x4 s;
+    uint32_t r[2][PASSES];
+    f32x4 s[2];
     const float* scale;
     Args args;
     int K, c, lrow;
@@ -204,34 +237,36 @@ struct LoaderBitsScale {
             rowp[i] = args.bits + static_cast<int64_t>(row) * args.words_ld;
         }
     }
+    template <int P>
     __device__ __forceinline__ void load(int kt) {
         const int k = kt * BK + 4 * c;
         if (KTAIL) {
             const bool ok = k < K;
             const int kk = ok ? k : 0;
             const f32x4 t = *reinterpret_cast<const f32x4*>(scale + kk);
-            s = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            s[P] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) {
                 const uint32_t w = rowp[i][kk >> 5];
-                r[i] = ok ? w : 0u;
+                r[P][i] = ok ? w : 0u;
             }
         } else {
-            s = *reinterpret_cast<const f32x4*>(scale + k);
+            s[P] = *reinterpret_cast<const f32x4*>(scale + k);
 #pragma unroll
-            for (int i = 0; i < PASSES; ++i) r[i] = rowp[i][k >> 5];
+            for (int i = 0; i < PASSES; ++i) r[P][i] = rowp[i][k >> 5];
         }
     }
+    template <int P>
     __device__ __forceinline__ void store(float* tile) const {
         const int sh = (4 * c) & 31;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            const uint32_t w = r[i] >> sh;
+            const uint32_t w = r[P][i] >> sh;
             f32x4 v;
-            v[0] = (w & 1u) ? s[0] : 0.f;
-            v[1] = (w & 2u) ? s[1] : 0.f;
-            v[2] = (w & 4u) ? s[2] : 0.f;
-            v[3] = (w & 8u) ? s[3] : 0.f;
+            v[0] = (w & 1u) ? s[P][0] : 0.f;
+            v[1] = (w & 2u) ? s[P][1] : 0.f;
+            v[2] = (w & 4u) ? s[P][2] : 0.f;
+            v[3] = (w & 8u) ? s[P][3] : 0.f;
             lds_store_chunk(tile + (i * G::ROWS_PER_PASS + lrow) * G::LDS_STRIDE, c, v);
         }
     }
@@ -286,7 +321,9 @@ __device__ __forceinline__ int mfma_row(int reg, int lane_half) {
 
 // 128x128 tiles are sized for two workgroups per CU (LDS 2 x 74 KB, <= 256 registers per lane):
 // the second launch-bounds argument (waves per SIMD) makes the register allocator honour that.
-template <class LA, class LB, class Epi, int BM, int BN, int BK>
+// ABLATE (diagnosis builds only, wrong results): 1 = no global loads / LDS writes inside the K loop,
+// 2 = additionally no LDS fragment reads (operands stay in registers): isolates the MFMA stream.
+template <class LA, class LB, class Epi, int BM, int BN, int BK, int ABLATE = 0>
 __global__ void __launch_bounds__(kGemmThreads, (BM * BN <= 128 * 128) ? 2 : 1)
 gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Args ea, int M, int N,
                    int K, SweepMap map) {
@@ -319,62 +356,102 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
     Epi epi;
     epi.begin(ea, ctx);
 
+    // Flat pipeline over steps s = (tile, kt): the LDS image of step s lives in buffer s & 1, the
+    // global loads of step s + 2 are issued at the top of step s into staging set s & 1 and are
+    // written to LDS at the end of step s + 1 -- two full MFMA phases to cover the L2/HBM latency.
     const int nk = (K + BK - 1) / BK;
-    a.load(0);
-    b.load(0);
-    a.store(smem);
-    b.store(smem + TILE_A);
+    const int nsteps = (m_last - m_first) * nk;
+    int ld_tile = m_first, ld_kt = 0;           // position of the load stream
+    auto issue_loads = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        a.template load<P>(ld_kt);
+        b.template load<P>(ld_kt);
+        if (++ld_kt == nk) {
+            ld_kt = 0;
+            ++ld_tile;
+            a.set_rows(ld_tile * BM);
+        }
+    };
+    issue_loads(std::integral_constant<int, 0>{});
+    if (nsteps > 1) issue_loads(std::integral_constant<int, 1>{});
+    if (LA::kAsmLoads || LB::kAsmLoads) {
+        constexpr int kYounger = LA::kLoadsPerStep + LB::kLoadsPerStep;
+        if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.template pin<0>();
+        b.template pin<0>();
+    }
+    a.template store<0>(smem);
+    b.template store<0>(smem + TILE_A);
     __syncthreads();
 
     const int arow = (ctx.wm * WTM + ctx.lane_col) * G::LDS_STRIDE + 4 * ctx.lane_half;
     const int brow = (ctx.wn * WTN + ctx.lane_col) * G::LDS_STRIDE + 4 * ctx.lane_half;
-    int buf = 0;
+    int tile = m_first, kt = 0;
+    f32x16 acc[MT][NT];
 
-#pragma unroll 1
-    for (int tile = m_first; tile < m_last; ++tile) {
-        ctx.m0 = tile * BM;
-        f32x16 acc[MT][NT];
-        epi.init(ea, acc, ctx);
-#pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            const float* sA = smem + buf * (TILE_A + TILE_B);
-            const float* sB = sA + TILE_A;
-            float* nA = smem + (buf ^ 1) * (TILE_A + TILE_B);
-            const bool last_k = (kt + 1) == nk;
-            const bool more = !last_k || (tile + 1) < m_last;
-            if (more) {
-                // next slice of this tile, or the first slice of the next tile of the sweep
-                if (last_k) a.set_rows((tile + 1) * BM);
-                a.load(last_k ? 0 : kt + 1);
-                b.load(last_k ? 0 : kt + 1);
-            }
+    auto step = [&](auto pc, int s_idx) {
+        constexpr int P = decltype(pc)::value;      // parity of this step: LDS buffer and staging set
+        const float* sA = smem + P * (TILE_A + TILE_B);
+        const float* sB = sA + TILE_A;
+        float* nA = smem + (P ^ 1) * (TILE_A + TILE_B);
+        if (kt == 0) {
+            ctx.m0 = tile * BM;
+            epi.init(ea, acc, ctx);
+        }
+        // staging set P held step s (already in LDS): refill it with step s + 2
+        if (ABLATE == 0 && s_idx + 2 < nsteps) issue_loads(pc);
 #pragma unroll
-            for (int g = 0; g < BK / 8; ++g) {
-                f32x4 af[MT], bf[NT];
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 af[MT], bf[NT];
+            if (ABLATE >= 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { af[mt] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(af[mt])); }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bf[nt] = f32x4{1.f, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(bf[nt])); }
+            } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     af[mt] = *reinterpret_cast<const f32x4*>(sA + arow + mt * 32 * G::LDS_STRIDE + 8 * g);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     bf[nt] = *reinterpret_cast<const f32x4*>(sB + brow + nt * 32 * G::LDS_STRIDE + 8 * g);
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t],
-                                                                               acc[mt][nt], 0, 0, 0);
             }
-            if (Epi::kCheckpoints) epi.checkpoint(ea, acc, ctx, (kt + 1) * BK);
-            if (more) {
-                a.store(nA);
-                b.store(nA + TILE_A);
-            }
-            __syncthreads();
-            buf ^= 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t], acc[mt][nt], 0, 0, 0);
         }
-        epi.finish(ea, acc, ctx);
+        if (Epi::kCheckpoints) epi.checkpoint(ea, acc, ctx, (kt + 1) * BK);
+        // step s + 1 (fetched during step s - 1) goes to the other LDS buffer
+        if (ABLATE == 0 && s_idx + 1 < nsteps) {
+            if (LA::kAsmLoads || LB::kAsmLoads) {
+                // Every VMEM op younger than set P^1's loads may stay in flight: the loads of set P
+                // issued at the top of this step (if any) -- anything else (epilogue stores, bias
+                // loads) only makes the wait stricter than necessary, never looser.
+                constexpr int kYounger = LA::kLoadsPerStep + LB::kLoadsPerStep;
+                if (s_idx + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                a.template pin<P ^ 1>();
+                b.template pin<P ^ 1>();
+            }
+            a.template store<P ^ 1>(nA);
+            b.template store<P ^ 1>(nA + TILE_A);
+        }
+        __syncthreads();
+        if (++kt == nk) {
+            epi.finish(ea, acc, ctx);
+            kt = 0;
+            ++tile;
+        }
+    };
+#pragma unroll 1
+    for (int s_idx = 0; s_idx < nsteps; s_idx += 2) {
+        step(std::integral_constant<int, 0>{}, s_idx);
+        if (s_idx + 1 < nsteps) step(std::integral_constant<int, 1>{}, s_idx + 1);
     }
     epi.end(ea, ctx);
 }
@@ -398,10 +475,10 @@ constexpr size_t gemm_lds_bytes(int epi_floats) {
 }
 
 // Host-side launcher.  sweep = number of consecutive R tiles per workgroup (<= 0: all of them).
-template <class LA, class LB, class Epi, int BM, int BN, int BK>
+template <class LA, class LB, class Epi, int BM, int BN, int BK, int ABLATE = 0>
 inline int launch_gemm(const typename LA::Args& la, const typename LB::Args& lb,
                        const typename Epi::Args& ea, int M, int N, int K, int sweep, hipStream_t stream) {
-    auto kern = gemm_nt_f32_kernel<LA, LB, Epi, BM, BN, BK>;
+    auto kern = gemm_nt_f32_kernel<LA, LB, Epi, BM, BN, BK, ABLATE>;
     constexpr size_t lds = gemm_lds_bytes<BM, BN, BK>(Epi::kLdsFloats);
     static bool configured = false;   // per instantiation
     if (!configured) {

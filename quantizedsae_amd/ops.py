@@ -44,6 +44,24 @@ class _KernelTimer:
 kernel_timer = _KernelTimer()
 
 
+def sweep_timing(enable: bool) -> None:
+    """Bracket the fused path's sweep kernel (launched inside qsae_encode_topk) with HIP events."""
+    lib = _lib.load()
+    lib.qsae_debug_sweep_timing.argtypes = [C.c_int]
+    lib.qsae_debug_sweep_timing(1 if enable else 0)
+
+
+def sweep_timing_collect(H: int):
+    """-> (mean ms per sweep launch or None, launches, fraction of the encoder FLOPs per launch)."""
+    lib = _lib.load()
+    lib.qsae_debug_sweep_timing_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.qsae_debug_sweep_flop_fraction.argtypes = [C.c_int]
+    lib.qsae_debug_sweep_flop_fraction.restype = C.c_double
+    tot, n = C.c_double(0.0), C.c_int(0)
+    lib.qsae_debug_sweep_timing_collect(C.byref(tot), C.byref(n))
+    return (tot.value / n.value if n.value else None), n.value, float(lib.qsae_debug_sweep_flop_fraction(H))
+
+
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")

@@ -26,8 +26,12 @@ class BaselineSparseAutoencoder(nn.Module):
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            h = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
-            idx, val = ops.topk_rows(h, self.topk, zero_rest=True)
+            if x.shape[0] >= 2048 and lin.weight.shape[0] >= 8192:
+                idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.topk)
+                h = ops.densify(idx, val, lin.weight.shape[0])
+            else:
+                h = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
+                idx, val = ops.topk_rows(h, self.topk, zero_rest=True)
             recon = ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
             return h, recon
 

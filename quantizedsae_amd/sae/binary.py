@@ -114,11 +114,25 @@ class BinarySAE(SparseAutoencoder):
             idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.top_k)
             return idx, val, self.decoder.decode_sparse(idx, val)
 
+    #: "auto" | "fused" | "inplace".  fused: encoder+top-k without a dense latent in HBM, the dense
+    #: [B,H] return value is then a memset + scatter; inplace: dense contraction, top-k masks it in
+    #: place.  Both give bit-identical outputs; auto takes fused for large batches.
+    latent_path = "auto"
+
     def forward(self, x):
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            latent = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
-            idx, val = ops.topk_rows(latent, self.top_k, zero_rest=True)     # latent * mask, in place
+            path = self.latent_path
+            if path == "auto":
+                path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
+            if path == "fused":
+                idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.top_k)
+                latent = ops.densify(idx, val, self.hidden_dim)
+            elif path == "inplace":
+                latent = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
+                idx, val = ops.topk_rows(latent, self.top_k, zero_rest=True)     # latent * mask, in place
+            else:
+                raise ValueError(f"latent_path must be 'auto', 'fused' or 'inplace', got {path!r}")
             recon = self.decoder.decode_sparse(idx, val)
             return latent, recon, self.decoder.packed()["polarize"]

@@ -52,7 +52,11 @@ def test_host_side_entry_points():
     assert lib.qsae_encode_dense(None, None, None, 4, 512, 32768, 0, None, 32768, None) == _lib.ERR_INVALID_ARG
     assert lib.qsae_topk_rows(ctypes.c_void_p(16), 32768, 1, 32768, 300, ctypes.c_void_p(16), ctypes.c_void_p(16),
                               1, None) == _lib.ERR_UNSUPPORTED
-    assert lib.qsae_encode_topk_workspace_bytes(65536, 512, 32768, 65) == 1024 * 32768 * 4
+    assert lib.qsae_encode_topk_workspace_bytes(512, 512, 32768, 65) == 512 * 32768 * 4        # chunked form
+    assert lib.qsae_encode_topk_workspace_bytes(1500, 512, 2048, 65) == 1024 * 2048 * 4
+    big = lib.qsae_encode_topk_workspace_bytes(65536, 512, 32768, 65)                          # fused form
+    assert 65536 * (2048 * 4 + 1024 * 8) < big < 2 * 1024 ** 3
+    assert lib.qsae_encode_topk_workspace_bytes(0, 512, 32768, 65) == 0
 
 
 def test_no_cpu_fallback():

@@ -43,8 +43,9 @@ def _reset_cfg():
 
 
 # ---- encoder ----------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [1, 2, 3])
-@pytest.mark.parametrize("B,D,H", [(300, 64, 1000), (256, 512, 2048), (257, 48, 520), (1, 512, 33), (513, 32, 257)])
+@pytest.mark.parametrize("cfg", [0])
+@pytest.mark.parametrize("B,D,H", [(300, 64, 1000), (256, 512, 2048), (257, 48, 520), (1, 512, 33), (513, 32, 257),
+                                   (1025, 512, 1280), (130, 96, 300)])
 def test_encode_dense_bitexact(cfg, B, D, H):
     ops = _ops()
     set_gemm_config(cfg)
@@ -74,7 +75,7 @@ def test_encode_dense_strided_out_and_empty():
     assert tuple(empty.shape) == (0, 96)
 
 
-@pytest.mark.parametrize("cfg", [1, 2])
+@pytest.mark.parametrize("cfg", [0])
 @pytest.mark.parametrize("B,D,H", [(300, 64, 1000), (130, 512, 4096), (5, 48, 70)])
 def test_encode_bits_bitexact(cfg, B, D, H):
     ops = _ops()

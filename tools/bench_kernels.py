@@ -38,11 +38,15 @@ def main():
     ap.add_argument("--k", type=int, default=65)
     ap.add_argument("--configs", default="1,2,3")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--sweeps", default="1,2,4,8,16,64")
+    ap.add_argument("--only-gemm", action="store_true")
     a = ap.parse_args()
     B, H, D, k = a.B, a.H, a.D, a.k
     dev = "cuda:0"
     lib = _lib.load()
     lib.qsae_debug_set_gemm_config.argtypes = [C.c_int]
+    lib.qsae_debug_set_sweep.argtypes = [C.c_int]
+    lib.qsae_debug_set_topk_path.argtypes = [C.c_int]
     torch.manual_seed(0)
     x = torch.randn(B, D, device=dev)
     bound = (6.0 / (D + H)) ** 0.5
@@ -59,6 +63,20 @@ def main():
                             tflops_med=flops / med / 1e9, tflops_best=flops / best / 1e9))
             print(json.dumps(res[-1]), flush=True)
     lib.qsae_debug_set_gemm_config(0)
+    for sweep in [int(v) for v in a.sweeps.split(",") if v]:
+        lib.qsae_debug_set_sweep(sweep)
+        med, best = timeit(lambda: ops.encode_dense(x, W, bias, ops.ACT_NONE, out=out), a.iters)
+        print(json.dumps(dict(kernel="encode_dense", cfg="auto", sweep=sweep, ms_med=med, ms_min=best,
+                              tflops_med=flops / med / 1e9)), flush=True)
+    lib.qsae_debug_set_sweep(0)
+    for path in (2, 1):
+        lib.qsae_debug_set_topk_path(path)
+        med, best = timeit(lambda: ops.encode_topk(x, W, bias, k), 3, 1)
+        print(json.dumps(dict(kernel="encode_topk", path={1: "chunked", 2: "fused"}[path], ms_med=med, ms_min=best,
+                              tflops=flops / med / 1e9)), flush=True)
+    lib.qsae_debug_set_topk_path(0)
+    if a.only_gemm:
+        return
     # top-k in place (needs fresh latents each time: time includes only the kernel, data stays the same shape)
     ops.encode_dense(x, W, bias, ops.ACT_NONE, out=out)
     lat = out.clone() if B * H * 4 < 60e9 else out
@@ -83,8 +101,6 @@ def main():
                           gatherGBps=B * k * 256 / med / 1e6)), flush=True)
     med, best = timeit(lambda: ops.densify(idx, val, H, out=out), a.iters)
     print(json.dumps(dict(kernel="densify(memset+scatter)", ms_med=med, GBps=B * H * 4 / med / 1e6)), flush=True)
-    med, best = timeit(lambda: ops.encode_topk(x, W, bias, k), 3, 1)
-    print(json.dumps(dict(kernel="encode_topk(chunked)", ms_med=med, ms_min=best, tflops=flops / med / 1e9)), flush=True)
     recon = ops.decode_binary_sparse(idx, val, packed, D, 4, 0.5, dbias)
     med, best = timeit(lambda: ops.sq_err_sum(recon, x), a.iters)
     print(json.dumps(dict(kernel="sq_err_sum", ms_med=med)), flush=True)
