@@ -12,6 +12,7 @@ namespace qsae {
 
 static int g_gemm_config = 0;   // kept for the debug ABI; only one tile shape is built
 int g_sweep_override = 0;       // 0 = heuristic (pick_sweep)
+int g_stagger = 0;              // start delay of the second co-resident block, x1024 cycles
 
 // ---- epilogues ------------------------------------------------------------------------
 template <int MT, int NT, int WTM, int WTN>
@@ -179,6 +180,11 @@ extern "C" int qsae_debug_encode_ablate(const float* x, const float* W, int B, i
     if (ablate == 2) QSAE_ABL(128, 128, 32, 2)
     QSAE_ABL(128, 128, 32, 0)
 #undef QSAE_ABL
+}
+
+extern "C" int qsae_debug_set_stagger(int units) {
+    g_stagger = units;
+    return QSAE_OK;
 }
 
 extern "C" int qsae_debug_set_sweep(int sweep) {

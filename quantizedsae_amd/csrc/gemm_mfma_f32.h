@@ -282,6 +282,7 @@ struct LoaderBitsScale {
 // XCD share Cm panels.  Bijective for any block count.  Speed only, never correctness.
 struct SweepMap {
     int tiles_m, tiles_n, sweep, msplit;    // msplit = ceil(tiles_m / sweep)
+    int stagger;                            // units of 1024 cycles of start delay for the 2nd co-resident block
     __device__ __forceinline__ void locate(int bid, int nblocks, int& tn, int& m_first, int& m_last) const {
         constexpr int NXCD = 8;
         const int q = nblocks / NXCD, rem = nblocks % NXCD;
@@ -345,6 +346,15 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
     ctx.M = M; ctx.N = N; ctx.K = K; ctx.tid = tid;
     ctx.lds_epi = smem + 2 * (TILE_A + TILE_B);
     ctx.m0 = m_first * BM;
+
+    // Two workgroups share a CU and run the same program: launched together they reach their
+    // barriers and LDS-write phases together and leave the matrix pipe idle together.  Blocks are
+    // dealt round-robin over 8 XCDs x 32 CUs, so bit 8 of the block id tells the first from the
+    // second block of a CU in the first dispatch wave; delaying the second one by about half a
+    // K step de-phases the pair (cdna microarch guide, "two waves per SIMD", item 9).  Speed only.
+    if (map.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < map.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     LA a;
     LB b;
@@ -459,6 +469,7 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
 // Sweep length heuristic for kernels without row ownership: long enough to amortise the pipeline
 // fill, short enough to leave >= ~2048 workgroups for load balance.  g_sweep_override > 0 forces it.
 extern int g_sweep_override;
+extern int g_stagger;
 template <int BM, int BN>
 inline int pick_sweep(int M, int N, int /*K*/) {
     if (g_sweep_override > 0) return g_sweep_override;
@@ -491,6 +502,7 @@ inline int launch_gemm(const typename LA::Args& la, const typename LB::Args& lb,
     map.tiles_n = (N + BN - 1) / BN;
     map.sweep = (sweep <= 0 || sweep > map.tiles_m) ? map.tiles_m : sweep;
     map.msplit = (map.tiles_m + map.sweep - 1) / map.sweep;
+    map.stagger = g_stagger;
     const long long nblocks = static_cast<long long>(map.tiles_n) * map.msplit;
     if (nblocks <= 0 || nblocks > 0x7FFFFFFFll) return fail(QSAE_ERR_UNSUPPORTED, "%s: tile count out of range", __func__);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kGemmThreads), lds, stream, la, lb,

@@ -26,18 +26,24 @@ def run(cfg, ab):
     assert rc == 0
 
 
+lib.qsae_debug_set_stagger.argtypes = [C.c_int]
+lib.qsae_debug_set_sweep.argtypes = [C.c_int]
 res = {}
+variants = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (0, 2, 0), (0, 4, 0), (0, 8, 0), (0, 4, 64), (0, 0, 64)]   # (ablate, stagger, sweep)
 for rnd in range(3):
-    for cfg in (2,):
-        for ab in (0, 1, 2):
-            run(cfg, ab)
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(3):
-                run(cfg, ab)
-            b.record(); b.synchronize()
-            res.setdefault((cfg, ab), []).append(a.elapsed_time(b) / 3)
-for (cfg, ab), ts in sorted(res.items()):
+    for ab, stg, swp in variants:
+        lib.qsae_debug_set_stagger(stg)
+        lib.qsae_debug_set_sweep(swp)
+        run(2, ab)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            run(2, ab)
+        b.record(); b.synchronize()
+        res.setdefault((ab, stg, swp), []).append(a.elapsed_time(b) / 3)
+lib.qsae_debug_set_stagger(0)
+lib.qsae_debug_set_sweep(0)
+for (ab, stg, swp), ts in sorted(res.items()):
     ms = sorted(ts)[len(ts) // 2]
-    print(json.dumps(dict(cfg=cfg, ablate=ab, ms=round(ms, 3), tflops=round(flops / ms / 1e9, 1))), flush=True)
+    print(json.dumps(dict(ablate=ab, stagger=stg, sweep=swp, ms=round(ms, 3), tflops=round(flops / ms / 1e9, 1))), flush=True)
