@@ -55,12 +55,22 @@ const char* qsae_last_error(void);
 int qsae_device_info(int* cu_count, char* arch, int arch_len);
 
 /* -- encoder ---------------------------------------------------------------------------- */
+/* K-interleaved operand layout.  dst[r][8g + j/2 + 4*(j&1)] = src[r][8g + j]: every 8 consecutive
+ * k of a row stored as [k0 k2 k4 k6 k1 k3 k5 k7] -- the order the fp32 MFMA consumes them from LDS,
+ * so that staged 16-byte chunks need no register shuffle.  Purely a storage permutation: the
+ * contraction still runs in ascending k and gives bit-identical results.  W_enc is permuted once
+ * per checkpoint, x once per batch (a 2 x B x D x 4-byte copy).  K % 8 == 0. */
+int qsae_kperm_rows(const float* src, int rows, int K, float* dst, qsae_stream_t stream);
+
 /* out[b][h] = act(bias[h] + sum_k x[b][k] * W[h][k])           (fp32 MFMA, exact fmaf chain)
  * Replaces nn.Linear (+ReLU / +Sigmoid) in SparseAutoencoder.encode, sae/base.py:16-19.
  * x [B][D], W [H][D], bias [H] or NULL, out [B][out_ld] with out_ld >= H.
  * Requires D % 4 == 0 and 16-byte aligned x, W. */
 int qsae_encode_dense(const float* x, const float* W, const float* bias, int B, int D, int H,
                       int act, float* out, int64_t out_ld, qsae_stream_t stream);
+/* Same with x and W already K-interleaved (qsae_kperm_rows); D % 32 == 0. */
+int qsae_encode_dense_kperm(const float* xp, const float* Wp, const float* bias, int B, int D, int H,
+                            int act, float* out, int64_t out_ld, qsae_stream_t stream);
 
 /* zbits[b][w] bit j = (sigmoid(pre[b][32w+j]) > 0.5) == (pre >= 0x33C00001), pre as above.
  * Replaces encoder(x) followed by `latent > 0.5`, sae/quantized_matryoshka.py:97-99,206-209
@@ -83,6 +93,10 @@ size_t qsae_encode_topk_workspace_bytes(int B, int D, int H, int k);
 int qsae_encode_topk(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
                      int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
                      qsae_stream_t stream);
+/* Same with x and W already K-interleaved (qsae_kperm_rows); D % 32 == 0. */
+int qsae_encode_topk_kperm(const float* xp, const float* Wp, const float* bias, int B, int D, int H, int k,
+                           int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
+                           qsae_stream_t stream);
 
 /* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
 int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,

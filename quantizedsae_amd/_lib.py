@@ -23,11 +23,14 @@ SIGNATURES = {
     "qsae_abi_version": (_i, []),
     "qsae_last_error": (C.c_char_p, []),
     "qsae_device_info": (_i, [C.POINTER(_i), C.c_char_p, _i]),
+    "qsae_kperm_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "qsae_encode_dense": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "qsae_encode_dense_kperm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_encode_bits": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_topk_rows": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp]),
     "qsae_encode_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "qsae_encode_topk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "qsae_encode_topk_kperm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "qsae_densify": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_binary_row_bytes": (_i, [_i, _i]),
     "qsae_pack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -109,7 +109,14 @@ struct EpiBits : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
 
 template <class Epi, int BM, int BN, int BK>
 static int run_encoder(const float* x, const float* W, int B, int D, int H, const typename Epi::Args& ea,
-                       hipStream_t s) {
+                       hipStream_t s, bool kperm = false) {
+    if (kperm) {     // operands stored K-interleaved: direct 16-byte LDS writes (D % BK == 0 checked by caller)
+        using LA = LoaderF32<BM, BK, false, true, true>;
+        using LB = LoaderF32<BN, BK, false, true, true>;
+        typename LA::Args la{x, D, B};
+        typename LB::Args lb{W, D, H};
+        return launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, B, H, D, pick_sweep<BM, BN>(B, H, D), s);
+    }
     if (D % BK == 0) {
         constexpr bool kAsm = (BM == 128 && BN == 128);     // audited spill-free instantiations only
         using LA = LoaderF32<BM, BK, false, kAsm>;
@@ -127,10 +134,10 @@ static int run_encoder(const float* x, const float* W, int B, int D, int H, cons
 
 template <int ACT, int BM, int BN, int BK>
 static int run_dense(const float* x, const float* W, const float* bias, int B, int D, int H, float* out,
-                     int64_t ld, hipStream_t s) {
+                     int64_t ld, hipStream_t s, bool kperm = false) {
     using Epi = EpiDense<ACT, BM, BN>;
     typename Epi::Args ea{bias, out, ld};
-    return run_encoder<Epi, BM, BN, BK>(x, W, B, D, H, ea, s);
+    return run_encoder<Epi, BM, BN, BK>(x, W, B, D, H, ea, s, kperm);
 }
 
 template <int BM, int BN, int BK>
@@ -147,8 +154,8 @@ static int run_bits(const float* x, const float* W, const float* bias, int B, in
 
 template <int ACT>
 static int dispatch_dense(const float* x, const float* W, const float* bias, int B, int D, int H, float* out,
-                          int64_t ld, hipStream_t s) {
-    return run_dense<ACT, 128, 128, 32>(x, W, bias, B, D, H, out, ld, s);
+                          int64_t ld, hipStream_t s, bool kperm = false) {
+    return run_dense<ACT, 128, 128, 32>(x, W, bias, B, D, H, out, ld, s, kperm);
 }
 
 }  // namespace qsae
@@ -192,21 +199,32 @@ extern "C" int qsae_debug_set_sweep(int sweep) {
     return QSAE_OK;
 }
 
-extern "C" int qsae_encode_dense(const float* x, const float* W, const float* bias, int B, int D, int H,
-                                 int act, float* out, int64_t out_ld, qsae_stream_t stream) {
+static int encode_dense_impl(const float* x, const float* W, const float* bias, int B, int D, int H, int act,
+                             float* out, int64_t out_ld, qsae_stream_t stream, bool kperm) {
     QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
     if (B == 0) return QSAE_OK;
     QSAE_CHECK_ARG(x && W && out, "null pointer");
     QSAE_CHECK_ARG(out_ld >= H, "out_ld < H");
     QSAE_CHECK_ARG(act >= QSAE_ACT_NONE && act <= QSAE_ACT_SIGMOID, "unknown activation");
     QSAE_CHECK_SUPPORTED(D % 4 == 0, "D must be a multiple of 4");
+    if (kperm) QSAE_CHECK_SUPPORTED(D % 32 == 0, "K-interleaved operands need D % 32 == 0");
     QSAE_CHECK_ARG(aligned16(x) && aligned16(W), "x and W must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
     switch (act) {
-        case QSAE_ACT_RELU: return dispatch_dense<QSAE_ACT_RELU>(x, W, bias, B, D, H, out, out_ld, s);
-        case QSAE_ACT_SIGMOID: return dispatch_dense<QSAE_ACT_SIGMOID>(x, W, bias, B, D, H, out, out_ld, s);
-        default: return dispatch_dense<QSAE_ACT_NONE>(x, W, bias, B, D, H, out, out_ld, s);
+        case QSAE_ACT_RELU: return dispatch_dense<QSAE_ACT_RELU>(x, W, bias, B, D, H, out, out_ld, s, kperm);
+        case QSAE_ACT_SIGMOID: return dispatch_dense<QSAE_ACT_SIGMOID>(x, W, bias, B, D, H, out, out_ld, s, kperm);
+        default: return dispatch_dense<QSAE_ACT_NONE>(x, W, bias, B, D, H, out, out_ld, s, kperm);
     }
+}
+
+extern "C" int qsae_encode_dense(const float* x, const float* W, const float* bias, int B, int D, int H,
+                                 int act, float* out, int64_t out_ld, qsae_stream_t stream) {
+    return encode_dense_impl(x, W, bias, B, D, H, act, out, out_ld, stream, false);
+}
+
+extern "C" int qsae_encode_dense_kperm(const float* xp, const float* Wp, const float* bias, int B, int D, int H,
+                                       int act, float* out, int64_t out_ld, qsae_stream_t stream) {
+    return encode_dense_impl(xp, Wp, bias, B, D, H, act, out, out_ld, stream, true);
 }
 
 extern "C" int qsae_encode_bits(const float* x, const float* W, const float* bias, int B, int D, int H,

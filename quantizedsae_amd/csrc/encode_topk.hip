@@ -240,11 +240,17 @@ scatter_topk_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ 
     val[static_cast<long long>(rows[r]) * k + j] = sval[gid];
 }
 
+static int dense(const float* x, const float* W, const float* bias, int B, int D, int H, float* out, int64_t ld,
+                 qsae_stream_t stream, bool kperm) {
+    return kperm ? qsae_encode_dense_kperm(x, W, bias, B, D, H, QSAE_ACT_NONE, out, ld, stream)
+                 : qsae_encode_dense(x, W, bias, B, D, H, QSAE_ACT_NONE, out, ld, stream);
+}
+
 static int run_chunked(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
-                       float* val, float* lat, qsae_stream_t stream) {
+                       float* val, float* lat, qsae_stream_t stream, bool kperm) {
     for (int b0 = 0; b0 < B; b0 += kChunkRows) {
         const int rows = (B - b0) < kChunkRows ? (B - b0) : kChunkRows;
-        int rc = qsae_encode_dense(x + static_cast<size_t>(b0) * D, W, bias, rows, D, H, QSAE_ACT_NONE, lat, H, stream);
+        int rc = dense(x + static_cast<size_t>(b0) * D, W, bias, rows, D, H, lat, H, stream, kperm);
         if (rc != QSAE_OK) return rc;
         rc = qsae_topk_rows(lat, H, rows, H, k, idx + static_cast<size_t>(b0) * k, val + static_cast<size_t>(b0) * k, 0,
                             stream);
@@ -254,7 +260,7 @@ static int run_chunked(const float* x, const float* W, const float* bias, int B,
 }
 
 static int run_fused(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
-                     float* val, char* ws, qsae_stream_t stream) {
+                     float* val, char* ws, qsae_stream_t stream, bool kperm) {
     hipStream_t s = as_stream(stream);
     const FusedLayout L = fused_layout(B, D, H, k);
     const int P = pilot_width(H);
@@ -265,7 +271,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     int* flags = reinterpret_cast<int*>(ws + L.flags);
     QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
     // 1. pilot block and per-row threshold
-    int rc = qsae_encode_dense(x, W, bias, B, D, P, QSAE_ACT_NONE, pilot, P, stream);
+    int rc = dense(x, W, bias, B, D, P, pilot, P, stream, kperm);
     if (rc != QSAE_OK) return rc;
     const int j = kPilotRank < P ? kPilotRank : P;
     rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, s);
@@ -282,7 +288,13 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             QSAE_HIP(hipEventCreate(&e1));
             QSAE_HIP(hipEventRecord(e0, s));
         }
-        if (D % BK == 0) {
+        if (kperm) {
+            using LA = LoaderF32<BM, BK, false, true, true>;
+            using LB = LoaderF32<BN, BK, false, true, true>;
+            typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
+            typename LB::Args lb{x, D, B};
+            rc = launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, Hs, B, D, /*sweep=*/0, s);
+        } else if (D % BK == 0) {
             using LA = LoaderF32<BM, BK, false, true>;
             using LB = LoaderF32<BN, BK, false, true>;
             typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
@@ -321,7 +333,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows,
                                n, D, fx);
             QSAE_LAUNCH_CHECK();
-            rc = qsae_encode_dense(fx, W, bias, n, D, H, QSAE_ACT_NONE, flat, H, stream);
+            rc = dense(fx, W, bias, n, D, H, flat, H, stream, kperm);
             if (rc != QSAE_OK) return rc;
             rc = qsae_topk_rows(flat, H, n, H, k, fidx, fval, 0, stream);
             if (rc != QSAE_OK) return rc;
@@ -376,9 +388,9 @@ extern "C" size_t qsae_encode_topk_workspace_bytes(int B, int D, int H, int k) {
     return rows * static_cast<size_t>(H) * sizeof(float);
 }
 
-extern "C" int qsae_encode_topk(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
-                                int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
-                                qsae_stream_t stream) {
+static int encode_topk_impl(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
+                            int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
+                            qsae_stream_t stream, bool kperm) {
     QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
     if (B == 0) return QSAE_OK;
     QSAE_CHECK_ARG(x && W && idx && val && workspace, "null pointer");
@@ -389,7 +401,20 @@ extern "C" int qsae_encode_topk(const float* x, const float* W, const float* bia
     if (use_fused(B, D, H, k)) {
         QSAE_CHECK_SUPPORTED(D % 4 == 0, "D must be a multiple of 4");
         QSAE_CHECK_ARG(aligned16(x) && aligned16(W), "x and W must be 16-byte aligned");
-        return run_fused(x, W, bias, B, D, H, k, idx, val, static_cast<char*>(workspace), stream);
+        return run_fused(x, W, bias, B, D, H, k, idx, val, static_cast<char*>(workspace), stream, kperm);
     }
-    return run_chunked(x, W, bias, B, D, H, k, idx, val, static_cast<float*>(workspace), stream);
+    return run_chunked(x, W, bias, B, D, H, k, idx, val, static_cast<float*>(workspace), stream, kperm);
+}
+
+extern "C" int qsae_encode_topk(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
+                                int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
+                                qsae_stream_t stream) {
+    return encode_topk_impl(x, W, bias, B, D, H, k, idx, val, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int qsae_encode_topk_kperm(const float* xp, const float* Wp, const float* bias, int B, int D, int H, int k,
+                                      int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
+                                      qsae_stream_t stream) {
+    if (D % 32 != 0) return fail(QSAE_ERR_UNSUPPORTED, "%s: K-interleaved operands need D %% 32 == 0", __func__);
+    return encode_topk_impl(xp, Wp, bias, B, D, H, k, idx, val, workspace, workspace_bytes, stream, true);
 }

@@ -57,7 +57,10 @@ __device__ __forceinline__ void lds_store_chunk(float* row, int c, f32x4 v) {
 
 // fp32 rows [nrows][ld], rows >= nrows are clamped (their outputs are never stored),
 // columns >= K read as zero (fma(0,0,acc) == acc keeps the chain exact).
-template <int ROWS, int BK, bool KTAIL = false, bool ASM = false>
+// KPERM: the operand is stored K-interleaved in memory (every 8 consecutive k as
+// [k0 k2 k4 k6 k1 k3 k5 k7], qsae_kperm_rows): a loaded 16-byte chunk is then already an LDS
+// chunk and goes out as ONE ds_write_b128 -- no register shuffling.
+template <int ROWS, int BK, bool KTAIL = false, bool ASM = false, bool KPERM = false>
 struct LoaderF32 {
     using G = TileGeom<BK>;
     static constexpr int PASSES = ROWS / G::ROWS_PER_PASS;
@@ -69,13 +72,16 @@ struct LoaderF32 {
     };
     // The hot (K % BK == 0) variant issues its loads from inline asm: hipcc cannot tell the two
     // staging sets apart across loop iterations and would drain the newer set with vmcnt(0);
-    // the kernel waits for them itself with a counted s_waitcnt (wait_staged below).
-    // Opt-in (ASM) and only for register-lean tiles: an asm load's destination must never be spilled
-    // or copied before the wait (cdna guide 5.7 item 1), which is audited per instantiation.
+    // the kernel waits for them itself with a counted s_waitcnt.  Opt-in (ASM) and only for
+    // register-lean tiles: an asm load's destination must never be spilled or copied before the
+    // wait (cdna guide 5.7 item 1), which is audited per instantiation (no scratch).  Addressing is
+    // SGPR base (operand + k offset, advanced with scalar adds) + one 32-bit VGPR byte offset per
+    // pass, so a K step costs no vector address arithmetic.
     static constexpr bool kAsmLoads = ASM && !KTAIL;
     static constexpr int kLoadsPerStep = PASSES;
-    const float* rowp[PASSES];
-    f32x4 r[2][PASSES];      // two staging sets: slices are fetched two steps ahead
+    const float* rowp[PASSES];       // compiler-load variants
+    uint32_t voff[PASSES];           // asm variant: byte offset of (row, chunk) from the operand base
+    f32x4 r[2][PASSES];              // two staging sets: slices are fetched two steps ahead
     Args args;
     int K, c, lrow;
 
@@ -91,7 +97,8 @@ struct LoaderF32 {
         for (int i = 0; i < PASSES; ++i) {
             int row = row0 + i * G::ROWS_PER_PASS + lrow;
             row = row < args.nrows ? row : args.nrows - 1;
-            rowp[i] = args.p + static_cast<int64_t>(row) * args.ld + 4 * c;
+            if (kAsmLoads) voff[i] = static_cast<uint32_t>((static_cast<int64_t>(row) * args.ld + 4 * c) * 4);
+            else rowp[i] = args.p + static_cast<int64_t>(row) * args.ld + 4 * c;
         }
     }
     // KTAIL = false (K % BK == 0, the hot configuration): plain loads, nothing consumes them
@@ -109,11 +116,10 @@ struct LoaderF32 {
                 r[P][i] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else if (ASM) {
+            const float* base = args.p + k0;      // wave-uniform: lives in an SGPR pair
 #pragma unroll
-            for (int i = 0; i < PASSES; ++i) {
-                const float* p = rowp[i] + k0;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[P][i]) : "v"(p) : "memory");
-            }
+            for (int i = 0; i < PASSES; ++i)
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r[P][i]) : "v"(voff[i]), "s"(base) : "memory");
         } else {
 #pragma unroll
             for (int i = 0; i < PASSES; ++i) r[P][i] = *reinterpret_cast<const f32x4*>(rowp[i] + k0);
@@ -130,8 +136,11 @@ struct LoaderF32 {
     template <int P>
     __device__ __forceinline__ void store(float* tile) const {
 #pragma unroll
-        for (int i = 0; i < PASSES; ++i)
-            lds_store_chunk(tile + (i * G::ROWS_PER_PASS + lrow) * G::LDS_STRIDE, c, r[P][i]);
+        for (int i = 0; i < PASSES; ++i) {
+            float* row = tile + (i * G::ROWS_PER_PASS + lrow) * G::LDS_STRIDE;
+            if (KPERM) *reinterpret_cast<f32x4*>(row + 4 * c) = r[P][i];
+            else lds_store_chunk(row, c, r[P][i]);
+        }
     }
 };
 

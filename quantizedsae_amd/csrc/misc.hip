@@ -48,6 +48,18 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
     if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(sum, acc);
 }
 
+// dst[r][8g + j/2 + 4*(j&1)] = src[r][8g + j]: every 8 consecutive k stored as [k0 k2 k4 k6 k1 k3 k5 k7],
+// the order in which v_mfma_f32_32x32x2_f32 wants them in LDS (gemm_mfma_f32.h).  One thread per group.
+__global__ void __launch_bounds__(256)
+kperm_rows_kernel(const float* __restrict__ src, long long groups, float* __restrict__ dst) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= groups) return;
+    const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * gid];
+    const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * gid + 1];
+    reinterpret_cast<f32x4*>(dst)[2 * gid] = f32x4{a[0], a[2], b[0], b[2]};
+    reinterpret_cast<f32x4*>(dst)[2 * gid + 1] = f32x4{a[1], a[3], b[1], b[3]};
+}
+
 // one wave per 64 words: lane l builds word (w0 + l) of a row from 32 consecutive floats
 __global__ void __launch_bounds__(256)
 pack_bits_gt_kernel(const float* __restrict__ dense, int64_t ld, int B, int H, float thr,
@@ -68,6 +80,19 @@ pack_bits_gt_kernel(const float* __restrict__ dense, int64_t ld, int B, int H, f
 }  // namespace qsae
 
 using namespace qsae;
+
+extern "C" int qsae_kperm_rows(const float* src, int rows, int K, float* dst, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(rows >= 0 && K > 0, "rows >= 0 and K > 0 required");
+    if (rows == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(src && dst && src != dst, "null or aliasing pointers");
+    QSAE_CHECK_SUPPORTED(K % 8 == 0, "K must be a multiple of 8");
+    QSAE_CHECK_ARG(aligned16(src) && aligned16(dst), "src and dst must be 16-byte aligned");
+    const long long groups = static_cast<long long>(rows) * (K / 8);
+    hipLaunchKernelGGL(kperm_rows_kernel, dim3(static_cast<unsigned>((groups + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), src, groups, dst);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
 
 extern "C" int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, float thr, uint32_t* zbits,
                                  int64_t words_ld, qsae_stream_t stream) {

@@ -85,8 +85,19 @@ def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
 
 
 # ---- encoder ------------------------------------------------------------------------------
+def kperm_rows(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K-interleaved copy of a [rows, K] fp32 matrix (K % 8 == 0); see qsae_kperm_rows."""
+    src = _f32c(src, "src")
+    rows, K = src.shape
+    if out is None:
+        out = torch.empty_like(src)
+    check(_lib.load().qsae_kperm_rows(_p(src), rows, K, _p(out), _stream()))
+    return out
+
+
 def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, kperm: bool = False) -> torch.Tensor:
+    """kperm=True: x and W are already K-interleaved (kperm_rows)."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
     B, D = x.shape
     H = W.shape[0]
@@ -98,8 +109,8 @@ def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     ev = kernel_timer.bracket("encode_dense") if kernel_timer.enabled else None
     if ev:
         ev[0].record()
-    check(_lib.load().qsae_encode_dense(_p(x), _p(W), _p(b), B, D, H, act, _p(out), out.stride(0) if B else H,
-                                        _stream()))
+    fn = _lib.load().qsae_encode_dense_kperm if kperm else _lib.load().qsae_encode_dense
+    check(fn(_p(x), _p(W), _p(b), B, D, H, act, _p(out), out.stride(0) if B else H, _stream()))
     if ev:
         ev[1].record()
     return out
@@ -141,7 +152,8 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], k: int):
+def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], k: int, kperm: bool = False):
+    """kperm=True: x and W are already K-interleaved (kperm_rows)."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
     B, D = x.shape
     H = W.shape[0]
@@ -151,7 +163,8 @@ def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], 
     ws = _workspace(x.device, need)
     idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
-    check(lib.qsae_encode_topk(_p(x), _p(W), _p(b), B, D, H, k, _p(idx), _p(val), _p(ws), ws.numel(), _stream()))
+    fn = lib.qsae_encode_topk_kperm if kperm else lib.qsae_encode_topk
+    check(fn(_p(x), _p(W), _p(b), B, D, H, k, _p(idx), _p(val), _p(ws), ws.numel(), _stream()))
     return idx, val
 
 

@@ -36,7 +36,19 @@ class HipEncoder(nn.Sequential):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         with torch.no_grad():
-            return ops.encode_dense(x, self[0].weight, self[0].bias, self._act)
+            xp, Wp, kperm = self.operands(x)
+            return ops.encode_dense(xp, Wp, self[0].bias, self._act, kperm=kperm)
+
+    def operands(self, x: torch.Tensor):
+        """(x', W', kperm): K-interleaved copies when the input width allows it (qsae_kperm_rows) -- W
+        once per checkpoint (cached on the parameter's version), x per call -- else the originals."""
+        W = self[0].weight
+        if W.shape[1] % 32 != 0 or not x.is_cuda:
+            return x, W, False
+        if not hasattr(self, "_kperm_cache"):
+            self._kperm_cache = PackedCache()
+        Wp = self._kperm_cache.get((W,), lambda: {"Wp": ops.kperm_rows(W.detach())})["Wp"]
+        return ops.kperm_rows(x), Wp, True
 
 
 class PackedCache:

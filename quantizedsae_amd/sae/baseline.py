@@ -27,10 +27,11 @@ class BaselineSparseAutoencoder(nn.Module):
             x = require_device_input(x, "x")
             lin = self.encoder.linear
             if x.shape[0] >= 2048 and lin.weight.shape[0] >= 8192:
-                idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.topk)
+                xp, Wp, kperm = self.encoder.operands(x)
+                idx, val = ops.encode_topk(xp, Wp, lin.bias, self.topk, kperm=kperm)
                 h = ops.densify(idx, val, lin.weight.shape[0])
             else:
-                h = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
+                h = self.encoder(x)
                 idx, val = ops.topk_rows(h, self.topk, zero_rest=True)
             recon = ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
             return h, recon
@@ -39,7 +40,8 @@ class BaselineSparseAutoencoder(nn.Module):
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.topk)
+            xp, Wp, kperm = self.encoder.operands(x)
+            idx, val = ops.encode_topk(xp, Wp, lin.bias, self.topk, kperm=kperm)
             return idx, val, ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
 
     def apply_topk_activation(self, h):

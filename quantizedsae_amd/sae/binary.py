@@ -111,7 +111,8 @@ class BinarySAE(SparseAutoencoder):
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.top_k)
+            xp, Wp, kperm = self.encoder.operands(x)
+            idx, val = ops.encode_topk(xp, Wp, lin.bias, self.top_k, kperm=kperm)
             return idx, val, self.decoder.decode_sparse(idx, val)
 
     #: "auto" | "fused" | "inplace".  fused: encoder+top-k without a dense latent in HBM, the dense
@@ -127,10 +128,11 @@ class BinarySAE(SparseAutoencoder):
             if path == "auto":
                 path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
             if path == "fused":
-                idx, val = ops.encode_topk(x, lin.weight, lin.bias, self.top_k)
+                xp, Wp, kperm = self.encoder.operands(x)
+                idx, val = ops.encode_topk(xp, Wp, lin.bias, self.top_k, kperm=kperm)
                 latent = ops.densify(idx, val, self.hidden_dim)
             elif path == "inplace":
-                latent = ops.encode_dense(x, lin.weight, lin.bias, ops.ACT_NONE)
+                latent = self.encoder(x)
                 idx, val = ops.topk_rows(latent, self.top_k, zero_rest=True)     # latent * mask, in place
             else:
                 raise ValueError(f"latent_path must be 'auto', 'fused' or 'inplace', got {path!r}")

@@ -346,3 +346,43 @@ def test_encode_topk_fused_fallback_rows(fused_path):
         want_idx, want_val = oracle.topk(oracle.encode(x, W, b_), k)
         assert np.array_equal(host(idx), want_idx)
         assert np.array_equal(host(val), want_val)
+
+
+# ---- K-interleaved operand layout ---------------------------------------------------------------------
+def _kperm_host(a):
+    r, K = a.shape
+    g = a.reshape(r, K // 8, 8)
+    return np.ascontiguousarray(g[:, :, [0, 2, 4, 6, 1, 3, 5, 7]].reshape(r, K))
+
+
+@pytest.mark.parametrize("B,D,H", [(300, 64, 1000), (257, 512, 2048), (1, 32, 33)])
+def test_kperm_rows_and_encode_dense_kperm(B, D, H):
+    ops = _ops()
+    x = S.activations(90, B, D)
+    W = S.xavier_uniform(90, H, D, stream=1)
+    bias = S.normal(90, (H,), stream=3, std=0.1)
+    xp, Wp = ops.kperm_rows(dev(x)), ops.kperm_rows(dev(W))
+    assert np.array_equal(host(xp), _kperm_host(x)) and np.array_equal(host(Wp), _kperm_host(W))
+    want = oracle.encode(x, W, bias)
+    assert np.array_equal(host(ops.encode_dense(xp, Wp, dev(bias), ops.ACT_NONE, kperm=True)), want)
+    assert np.array_equal(host(ops.encode_dense(xp, Wp, dev(bias), ops.ACT_RELU, kperm=True)), np.maximum(want, 0))
+    from quantizedsae_amd import _lib
+    with pytest.raises(_lib.QsaeError):
+        ops.kperm_rows(torch.zeros((4, 12), device=DEV))          # K % 8 != 0
+
+
+@pytest.mark.parametrize("B,D,H,k", [(1000, 512, 8192, 65), (300, 64, 4096, 8)])
+def test_encode_topk_kperm_fused_and_chunked(B, D, H, k):
+    ops = _ops()
+    x = S.activations(91, B, D)
+    W = S.xavier_uniform(91, H, D, stream=1)
+    bias = S.normal(91, (H,), stream=3, std=0.05)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    xp, Wp = ops.kperm_rows(dev(x)), ops.kperm_rows(dev(W))
+    for path in (2, 1):
+        set_topk_path(path)
+        try:
+            idx, val = ops.encode_topk(xp, Wp, dev(bias), k, kperm=True)
+        finally:
+            set_topk_path(0)
+        assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Fused encoder+top-k timing under tuning knobs (stagger), interleaved rounds in one process."""
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from quantizedsae_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+lib.qsae_debug_set_stagger.argtypes = [C.c_int]
+B, D, H, k = 65536, 512, 32768, 65
+x = torch.randn(B, D, device="cuda:0")
+W = (torch.rand(H, D, device="cuda:0") * 2 - 1) * (6.0 / (D + H)) ** 0.5
+bias = torch.zeros(H, device="cuda:0")
+res = {}
+Wp = ops.kperm_rows(W)
+xp = ops.kperm_rows(x)
+for rnd in range(4):
+    for kperm in (False, True):
+        a_x, a_W = (xp, Wp) if kperm else (x, W)
+        ops.encode_topk(a_x, a_W, bias, k, kperm=kperm)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.sweep_timing(True)
+        e0.record()
+        for _ in range(3):
+            if kperm:
+                ops.kperm_rows(x, out=xp)       # the per-batch permutation is part of the cost
+            ops.encode_topk(a_x, a_W, bias, k, kperm=kperm)
+        e1.record(); e1.synchronize()
+        ops.sweep_timing(False)
+        ms, n, frac = ops.sweep_timing_collect(H)
+        res.setdefault(kperm, []).append((ms, e0.elapsed_time(e1) / 3))
+for kperm, ts in sorted(res.items()):
+    ms = sorted(t[0] for t in ts)[len(ts) // 2]
+    tot = sorted(t[1] for t in ts)[len(ts) // 2]
+    print(json.dumps(dict(kperm=kperm, sweep_ms=round(ms, 3), sweep_tflops=round(frac * 2.0 * B * D * H / ms / 1e9, 1),
+                          encode_topk_total_ms=round(tot, 3))), flush=True)
