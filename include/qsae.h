@@ -98,6 +98,15 @@ int qsae_encode_topk_kperm(const float* xp, const float* Wp, const float* bias, 
                            int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
                            qsae_stream_t stream);
 
+/* qsae_encode_topk plus the reference's dense return value: dense[b][h] = latent if h is one of row
+ * b's top-k else +0 (`latent * mask`, sae/binary.py:96-99; `zeros_like + scatter_`,
+ * sae/baseline.py:38-40).  In the fused form the sweep zero-fills the dense tensor tile by tile
+ * underneath its own MFMAs and the k survivors are scattered in at the end -- no separate memset
+ * pass, no dense latent read back.  kperm != 0: x and W are K-interleaved.  Same workspace. */
+int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
+                            int32_t* idx, float* val, float* dense, int64_t dense_ld, int kperm,
+                            void* workspace, size_t workspace_bytes, qsae_stream_t stream);
+
 /* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
 int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
                  qsae_stream_t stream);

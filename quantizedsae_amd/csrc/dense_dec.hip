@@ -39,6 +39,7 @@ struct EpiStore {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
     static constexpr int kLdsFloats = 0;
+    static constexpr int kStoresPerFinish = 0;   // conservative: the staged-load wait then also covers them
     template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
     template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {
@@ -124,6 +125,7 @@ struct EpiLevels {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 1;
     static constexpr int kLdsFloats = 0;
+    static constexpr int kStoresPerFinish = 0;   // conservative: the staged-load wait then also covers them
     template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
     template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {

@@ -37,6 +37,7 @@ struct EpiDense : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
     static constexpr int kLdsFloats = 0;
+    static constexpr int kStoresPerFinish = 0;   // conservative: the staged-load wait then also covers them
     template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
     template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {
@@ -74,6 +75,7 @@ struct EpiBits : EpiBase<BM / 64, BN / 64, BM / 2, BN / 2> {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
     static constexpr int kLdsFloats = 0;
+    static constexpr int kStoresPerFinish = 0;   // conservative: the staged-load wait then also covers them
     template <class A> __device__ __forceinline__ void begin(const A&, const TileCtx&) {}
     template <class A> __device__ __forceinline__ void end(const A&, const TileCtx&) {}
     struct Args {

@@ -26,6 +26,7 @@ namespace qsae {
 
 int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
                        float* tau, uint2* cand, int* cnt, int cap, hipStream_t s);
+int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
 constexpr int kCandCap = 1024;     // candidate slots per row
@@ -81,6 +82,7 @@ struct EpiFilter {
     static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
     static constexpr int kCheckpoints = 0;
     static constexpr int kLdsFloats = BN;      // per-row candidate counters
+    static constexpr int kStoresPerFinish = (BM * BN * 4) / (4 * 1024);   // zero-fill: 1 KiB per wave store
     struct Args {
         const float* bias;   // [hidden], already offset to the first swept hidden unit (may be null)
         const float* tau;    // [B]
@@ -88,6 +90,8 @@ struct EpiFilter {
         int* cnt;            // [B]  in: candidates already present, out: total
         int cap;
         int hidden_offset;   // index of the first swept hidden unit
+        float* dense;        // optional [B][dense_ld]: the tile's block of the dense latent is zero-filled
+        int64_t dense_ld;    //   here (the k survivors are scattered in afterwards); nullptr = no dense output
     };
     float tau[NT];
     bool col_ok[NT];
@@ -121,6 +125,22 @@ struct EpiFilter {
     __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
     __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
         int* counters = reinterpret_cast<int*>(c.lds_epi);
+        if (a.dense != nullptr) {
+            // The reference returns latent*mask as a dense [B, H] tensor (sae/binary.py:96-99): 99.8 %
+            // zeros.  Each tile zero-fills its own BN x BM block with fire-and-forget 16-byte stores that
+            // ride under the next tile's MFMAs, instead of a separate 8 GiB memset pass.
+            // wave w covers rows [32w, 32w+32) of the panel; one store = 2 rows x 512 B.
+            const int wave = c.wm * 2 + c.wn, lane = c.lane_half * 32 + c.lane_col;
+            const int h0 = c.m0 + a.hidden_offset;               // first hidden unit of this tile
+            const int col = h0 + 4 * (lane & 31);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < (BN / 4) / 2; ++i) {
+                const int row = c.n0 + wave * (BN / 4) + 2 * i + (lane >> 5);
+                if (row < c.N && (c.m0 + 4 * (lane & 31)) < c.M)
+                    *reinterpret_cast<f32x4*>(a.dense + static_cast<int64_t>(row) * a.dense_ld + col) = z;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int lcol = c.wn * WTN + nt * 32 + c.lane_col;
@@ -240,7 +260,7 @@ scatter_topk_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ 
     val[static_cast<long long>(rows[r]) * k + j] = sval[gid];
 }
 
-static int dense(const float* x, const float* W, const float* bias, int B, int D, int H, float* out, int64_t ld,
+static int dense_latent(const float* x, const float* W, const float* bias, int B, int D, int H, float* out, int64_t ld,
                  qsae_stream_t stream, bool kperm) {
     return kperm ? qsae_encode_dense_kperm(x, W, bias, B, D, H, QSAE_ACT_NONE, out, ld, stream)
                  : qsae_encode_dense(x, W, bias, B, D, H, QSAE_ACT_NONE, out, ld, stream);
@@ -250,7 +270,7 @@ static int run_chunked(const float* x, const float* W, const float* bias, int B,
                        float* val, float* lat, qsae_stream_t stream, bool kperm) {
     for (int b0 = 0; b0 < B; b0 += kChunkRows) {
         const int rows = (B - b0) < kChunkRows ? (B - b0) : kChunkRows;
-        int rc = dense(x + static_cast<size_t>(b0) * D, W, bias, rows, D, H, lat, H, stream, kperm);
+        int rc = dense_latent(x + static_cast<size_t>(b0) * D, W, bias, rows, D, H, lat, H, stream, kperm);
         if (rc != QSAE_OK) return rc;
         rc = qsae_topk_rows(lat, H, rows, H, k, idx + static_cast<size_t>(b0) * k, val + static_cast<size_t>(b0) * k, 0,
                             stream);
@@ -260,7 +280,7 @@ static int run_chunked(const float* x, const float* W, const float* bias, int B,
 }
 
 static int run_fused(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
-                     float* val, char* ws, qsae_stream_t stream, bool kperm) {
+                     float* val, char* ws, qsae_stream_t stream, bool kperm, float* dense, int64_t dense_ld) {
     hipStream_t s = as_stream(stream);
     const FusedLayout L = fused_layout(B, D, H, k);
     const int P = pilot_width(H);
@@ -271,7 +291,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     int* flags = reinterpret_cast<int*>(ws + L.flags);
     QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
     // 1. pilot block and per-row threshold
-    int rc = dense(x, W, bias, B, D, P, pilot, P, stream, kperm);
+    int rc = dense_latent(x, W, bias, B, D, P, pilot, P, stream, kperm);
     if (rc != QSAE_OK) return rc;
     const int j = kPilotRank < P ? kPilotRank : P;
     rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, s);
@@ -280,7 +300,9 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     {
         constexpr int BM = 128, BN = 128, BK = 32;
         using Epi = EpiFilter<BM, BN>;
-        typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P};
+        if (dense)   // pilot columns of the dense latent: the sweep only visits hidden units >= P
+            QSAE_HIP(hipMemset2DAsync(dense, static_cast<size_t>(dense_ld) * 4, 0, static_cast<size_t>(P) * 4, B, s));
+        typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld};
         const int Hs = H - P;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_time_sweep) {
@@ -333,7 +355,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows,
                                n, D, fx);
             QSAE_LAUNCH_CHECK();
-            rc = dense(fx, W, bias, n, D, H, flat, H, stream, kperm);
+            rc = dense_latent(fx, W, bias, n, D, H, flat, H, stream, kperm);
             if (rc != QSAE_OK) return rc;
             rc = qsae_topk_rows(flat, H, n, H, k, fidx, fval, 0, stream);
             if (rc != QSAE_OK) return rc;
@@ -343,6 +365,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             QSAE_LAUNCH_CHECK();
         }
     }
+    if (dense) return scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
 }
 
@@ -390,7 +413,7 @@ extern "C" size_t qsae_encode_topk_workspace_bytes(int B, int D, int H, int k) {
 
 static int encode_topk_impl(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
                             int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
-                            qsae_stream_t stream, bool kperm) {
+                            qsae_stream_t stream, bool kperm, float* dense = nullptr, int64_t dense_ld = 0) {
     QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
     if (B == 0) return QSAE_OK;
     QSAE_CHECK_ARG(x && W && idx && val && workspace, "null pointer");
@@ -401,9 +424,23 @@ static int encode_topk_impl(const float* x, const float* W, const float* bias, i
     if (use_fused(B, D, H, k)) {
         QSAE_CHECK_SUPPORTED(D % 4 == 0, "D must be a multiple of 4");
         QSAE_CHECK_ARG(aligned16(x) && aligned16(W), "x and W must be 16-byte aligned");
-        return run_fused(x, W, bias, B, D, H, k, idx, val, static_cast<char*>(workspace), stream, kperm);
+        if (dense) {
+            QSAE_CHECK_ARG(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense), "dense latent must be 16-byte aligned with ld >= H, ld % 4 == 0");
+        }
+        return run_fused(x, W, bias, B, D, H, k, idx, val, static_cast<char*>(workspace), stream, kperm, dense, dense_ld);
     }
-    return run_chunked(x, W, bias, B, D, H, k, idx, val, static_cast<float*>(workspace), stream, kperm);
+    const int rc = run_chunked(x, W, bias, B, D, H, k, idx, val, static_cast<float*>(workspace), stream, kperm);
+    if (rc != QSAE_OK || !dense) return rc;
+    return qsae_densify(idx, val, B, k, H, dense, dense_ld, stream);
+}
+
+extern "C" int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
+                                       int32_t* idx, float* val, float* dense, int64_t dense_ld, int kperm,
+                                       void* workspace, size_t workspace_bytes, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(dense != nullptr && dense_ld >= H, "dense latent pointer / leading dimension");
+    if (kperm && D % 32 != 0) return fail(QSAE_ERR_UNSUPPORTED, "%s: K-interleaved operands need D %% 32 == 0", __func__);
+    return encode_topk_impl(x, W, bias, B, D, H, k, idx, val, workspace, workspace_bytes, stream, kperm != 0, dense,
+                            dense_ld);
 }
 
 extern "C" int qsae_encode_topk(const float* x, const float* W, const float* bias, int B, int D, int H, int k,

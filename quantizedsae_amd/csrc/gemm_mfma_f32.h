@@ -369,8 +369,11 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
     LB b;
     a.init(la, K, tid);
     b.init(lb, K, tid);
-    a.set_rows(ctx.m0);
-    b.set_rows(ctx.n0);
+    // diagnosis (stagger == -1/-2, wrong results): every workgroup streams the SAME operand rows, i.e.
+    // all staging loads hit L2 -- separates "memory supply" from "instruction stream" losses
+    const bool same_a = map.stagger < 0, same_b = map.stagger == -1;
+    a.set_rows(same_a ? 0 : ctx.m0);
+    b.set_rows(same_b ? 0 : ctx.n0);
 
     Epi epi;
     epi.begin(ea, ctx);
@@ -388,7 +391,7 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
         if (++ld_kt == nk) {
             ld_kt = 0;
             ++ld_tile;
-            a.set_rows(ld_tile * BM);
+            a.set_rows(same_a ? 0 : ld_tile * BM);
         }
     };
     issue_loads(std::integral_constant<int, 0>{});
@@ -408,6 +411,7 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
     const int brow = (ctx.wn * WTN + ctx.lane_col) * G::LDS_STRIDE + 4 * ctx.lane_half;
     int tile = m_first, kt = 0;
     f32x16 acc[MT][NT];
+    constexpr int kStoreAfterG = (BK / 8 >= 2) ? (BK / 8) / 2 - 1 : 0;   // LDS writes after the first half
 
     auto step = [&](auto pc, int s_idx) {
         constexpr int P = decltype(pc)::value;      // parity of this step: LDS buffer and staging set
@@ -443,23 +447,31 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t], acc[mt][nt], 0, 0, 0);
+            // Mid-step: step s + 1 (fetched during step s - 1) goes to the other LDS buffer.  Nobody
+            // reads that buffer during step s (its last readers passed the barrier that ended step
+            // s - 1), so the LDS writes ride under this wave's remaining MFMAs instead of forming a
+            // serial tail in front of the barrier.
+            if (g == kStoreAfterG && ABLATE == 0 && s_idx + 1 < nsteps) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (LA::kAsmLoads || LB::kAsmLoads) {
+                    // Every VMEM op younger than set P^1's loads may stay in flight: the loads of set
+                    // P issued at the top of this step (if any) -- anything else (epilogue stores, bias
+                    // loads) only makes the wait stricter than necessary, never looser.
+                    constexpr int kYounger = LA::kLoadsPerStep + LB::kLoadsPerStep;
+                    // first step after an epilogue: its fire-and-forget stores sit between the two sets
+                    constexpr int kAfterEpi = (kYounger + Epi::kStoresPerFinish) < 63 ? (kYounger + Epi::kStoresPerFinish) : 63;
+                    if (s_idx + 2 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (kt == 0 && Epi::kStoresPerFinish > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAfterEpi) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
+                    a.template pin<P ^ 1>();
+                    b.template pin<P ^ 1>();
+                }
+                a.template store<P ^ 1>(nA);
+                b.template store<P ^ 1>(nA + TILE_A);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (Epi::kCheckpoints) epi.checkpoint(ea, acc, ctx, (kt + 1) * BK);
-        // step s + 1 (fetched during step s - 1) goes to the other LDS buffer
-        if (ABLATE == 0 && s_idx + 1 < nsteps) {
-            if (LA::kAsmLoads || LB::kAsmLoads) {
-                // Every VMEM op younger than set P^1's loads may stay in flight: the loads of set P
-                // issued at the top of this step (if any) -- anything else (epilogue stores, bias
-                // loads) only makes the wait stricter than necessary, never looser.
-                constexpr int kYounger = LA::kLoadsPerStep + LB::kLoadsPerStep;
-                if (s_idx + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                a.template pin<P ^ 1>();
-                b.template pin<P ^ 1>();
-            }
-            a.template store<P ^ 1>(nA);
-            b.template store<P ^ 1>(nA + TILE_A);
-        }
         __syncthreads();
         if (++kt == nk) {
             epi.finish(ea, acc, ctx);

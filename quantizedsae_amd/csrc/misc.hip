@@ -77,6 +77,16 @@ pack_bits_gt_kernel(const float* __restrict__ dense, int64_t ld, int B, int H, f
     zbits[b * words_ld + wi] = word;
 }
 
+// scatter without the preceding zero fill (the fused encoder zero-fills the dense latent itself)
+int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s) {
+    const long long total = static_cast<long long>(B) * k;
+    if (total == 0) return QSAE_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, idx,
+                       val, total, k, H, dense, ld);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
 }  // namespace qsae
 
 using namespace qsae;

@@ -168,6 +168,23 @@ def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], 
     return idx, val
 
 
+def encode_topk_latent(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], k: int, kperm: bool = False):
+    """-> (idx, val, dense latent [B,H]); the dense tensor is zero-filled inside the encoder sweep."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    lib = _lib.load()
+    need = int(lib.qsae_encode_topk_workspace_bytes(B, D, H, k))
+    ws = _workspace(x.device, need)
+    idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=x.device)
+    dense = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    check(lib.qsae_encode_topk_latent(_p(x), _p(W), _p(b), B, D, H, k, _p(idx), _p(val), _p(dense), H,
+                                      1 if kperm else 0, _p(ws), ws.numel(), _stream()))
+    return idx, val, dense
+
+
 def densify(idx: torch.Tensor, val: torch.Tensor, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(idx, "idx", torch.int32)
     _dev(val, "val", torch.float32)

@@ -28,8 +28,7 @@ class BaselineSparseAutoencoder(nn.Module):
             lin = self.encoder.linear
             if x.shape[0] >= 2048 and lin.weight.shape[0] >= 8192:
                 xp, Wp, kperm = self.encoder.operands(x)
-                idx, val = ops.encode_topk(xp, Wp, lin.bias, self.topk, kperm=kperm)
-                h = ops.densify(idx, val, lin.weight.shape[0])
+                idx, val, h = ops.encode_topk_latent(xp, Wp, lin.bias, self.topk, kperm=kperm)
             else:
                 h = self.encoder(x)
                 idx, val = ops.topk_rows(h, self.topk, zero_rest=True)

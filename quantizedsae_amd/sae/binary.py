@@ -129,8 +129,7 @@ class BinarySAE(SparseAutoencoder):
                 path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
             if path == "fused":
                 xp, Wp, kperm = self.encoder.operands(x)
-                idx, val = ops.encode_topk(xp, Wp, lin.bias, self.top_k, kperm=kperm)
-                latent = ops.densify(idx, val, self.hidden_dim)
+                idx, val, latent = ops.encode_topk_latent(xp, Wp, lin.bias, self.top_k, kperm=kperm)
             elif path == "inplace":
                 latent = self.encoder(x)
                 idx, val = ops.topk_rows(latent, self.top_k, zero_rest=True)     # latent * mask, in place

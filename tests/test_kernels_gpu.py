@@ -386,3 +386,20 @@ def test_encode_topk_kperm_fused_and_chunked(B, D, H, k):
         finally:
             set_topk_path(0)
         assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)
+
+
+@pytest.mark.parametrize("B,D,H,k,kperm", [(1000, 512, 8192, 65, True), (300, 64, 4096, 8, False), (70, 64, 1000, 2, False)])
+def test_encode_topk_latent_dense_output(fused_path, B, D, H, k, kperm):
+    """encoder + top-k + the reference's dense `latent * mask` in one call (zero-fill fused in the sweep)."""
+    ops = _ops()
+    x = S.activations(92, B, D)
+    W = S.xavier_uniform(92, H, D, stream=1)
+    bias = S.normal(92, (H,), stream=3, std=0.05)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    a_x, a_W = (ops.kperm_rows(dev(x)), ops.kperm_rows(dev(W))) if kperm else (dev(x), dev(W))
+    torch.cuda.synchronize()
+    poison = torch.full((B, H), 7.0, device=DEV)            # make sure every element gets written
+    del poison
+    idx, val, dense = ops.encode_topk_latent(a_x, a_W, dev(bias), k, kperm=kperm)
+    assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)
+    assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
