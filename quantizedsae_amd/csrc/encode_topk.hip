@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "gemm_mfma_f32.h"
+#include "gemm_mfma_f32_dma.h"
 
 namespace qsae {
 
@@ -34,6 +35,7 @@ constexpr int kPilotRank = 20;     // tau = kPilotRank-th largest pilot value
 constexpr int kFusedMinRows = 2048;
 constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
+static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 
 // Optional HIP-event bracket around the sweep kernel (bench.py's live roofline measurement): events
 // are recorded on the launch stream and only read by qsae_debug_sweep_timing_collect().
@@ -77,12 +79,13 @@ static FusedLayout fused_layout(int B, int D, int H, int k) {
 }
 
 // ---- sweep epilogue: threshold filter ---------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int WMW = 2, int WNW = 2>
 struct EpiFilter {
-    static constexpr int MT = BM / 64, NT = BN / 64, WTM = BM / 2, WTN = BN / 2;
+    static constexpr int WTM = BM / WMW, WTN = BN / WNW, MT = WTM / 32, NT = WTN / 32;
+    static constexpr int kThreads = 64 * WMW * WNW;
     static constexpr int kCheckpoints = 0;
     static constexpr int kLdsFloats = BN;      // per-row candidate counters
-    static constexpr int kStoresPerFinish = (BM * BN * 4) / (4 * 1024);   // zero-fill: 1 KiB per wave store
+    static constexpr int kStoresPerFinish = (BM * BN * 4) / (kThreads * 16);   // zero-fill stores per wave
     struct Args {
         const float* bias;   // [hidden], already offset to the first swept hidden unit (may be null)
         const float* tau;    // [B]
@@ -128,17 +131,17 @@ struct EpiFilter {
         if (a.dense != nullptr) {
             // The reference returns latent*mask as a dense [B, H] tensor (sae/binary.py:96-99): 99.8 %
             // zeros.  Each tile zero-fills its own BN x BM block with fire-and-forget 16-byte stores that
-            // ride under the next tile's MFMAs, instead of a separate 8 GiB memset pass.
-            // wave w covers rows [32w, 32w+32) of the panel; one store = 2 rows x 512 B.
-            const int wave = c.wm * 2 + c.wn, lane = c.lane_half * 32 + c.lane_col;
+            // ride under the next tile's MFMAs, instead of a separate 8 GiB memset pass.  Thread t takes
+            // the 16-byte chunks t, t + T, ...; consecutive threads -> consecutive chunks of one row.
+            constexpr int CPR = BM / 4;                           // chunks per row of the block
             const int h0 = c.m0 + a.hidden_offset;               // first hidden unit of this tile
-            const int col = h0 + 4 * (lane & 31);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < (BN / 4) / 2; ++i) {
-                const int row = c.n0 + wave * (BN / 4) + 2 * i + (lane >> 5);
-                if (row < c.N && (c.m0 + 4 * (lane & 31)) < c.M)
-                    *reinterpret_cast<f32x4*>(a.dense + static_cast<int64_t>(row) * a.dense_ld + col) = z;
+            for (int i = 0; i < (BN * CPR) / kThreads; ++i) {
+                const int chunk = i * kThreads + c.tid;
+                const int row = c.n0 + chunk / CPR, cc = 4 * (chunk % CPR);
+                if (row < c.N && (c.m0 + cc) < c.M)
+                    *reinterpret_cast<f32x4*>(a.dense + static_cast<int64_t>(row) * a.dense_ld + h0 + cc) = z;
             }
         }
 #pragma unroll
@@ -310,7 +313,11 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             QSAE_HIP(hipEventCreate(&e1));
             QSAE_HIP(hipEventRecord(e0, s));
         }
-        if (kperm) {
+        if (kperm && g_sweep_kernel == 0 && D % kDmaBK == 0) {
+            using EpiD = EpiFilter<256, 128, 4, 2>;
+            typename EpiD::Args ed{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld};
+            rc = launch_gemm_dma<EpiD, 256, 128>(W + static_cast<size_t>(P) * D, Hs, x, B, D, ed, s);
+        } else if (kperm) {
             using LA = LoaderF32<BM, BK, false, true, true>;
             using LB = LoaderF32<BN, BK, false, true, true>;
             typename LA::Args la{W + static_cast<size_t>(P) * D, D, Hs};
@@ -397,6 +404,11 @@ extern "C" int qsae_debug_sweep_timing_collect(double* total_ms, int* launches) 
 // fraction of the encoder FLOPs the sweep launch covers (the pilot block takes the rest)
 extern "C" double qsae_debug_sweep_flop_fraction(int H) {
     return static_cast<double>(H - pilot_width(H)) / static_cast<double>(H);
+}
+
+extern "C" int qsae_debug_set_sweep_kernel(int which) {
+    g_sweep_kernel = which;
+    return QSAE_OK;
 }
 
 extern "C" int qsae_debug_set_topk_path(int path) {

@@ -21,9 +21,10 @@ res = {}
 Wp = ops.kperm_rows(W)
 xp = ops.kperm_rows(x)
 lib.qsae_debug_set_stagger.argtypes = [C.c_int]
+lib.qsae_debug_set_sweep_kernel.argtypes = [C.c_int]
 for rnd in range(4):
-    for kperm in (True,):
-        lib.qsae_debug_set_stagger(0 if kperm is True else kperm)
+    for kperm in ("dma", "regstage"):
+        lib.qsae_debug_set_sweep_kernel(0 if kperm == "dma" else 1)
         a_x, a_W = (xp, Wp)
         ops.encode_topk(a_x, a_W, bias, k, kperm=True)
         torch.cuda.synchronize()
@@ -36,7 +37,7 @@ for rnd in range(4):
         ops.sweep_timing(False)
         ms, n, frac = ops.sweep_timing_collect(H)
         res.setdefault(kperm, []).append((ms, e0.elapsed_time(e1) / 3))
-lib.qsae_debug_set_stagger(0)
+lib.qsae_debug_set_sweep_kernel(0)
 for kperm, ts in sorted(res.items(), key=lambda kv: str(kv[0])):
     ms = sorted(t[0] for t in ts)[len(ts) // 2]
     tot = sorted(t[1] for t in ts)[len(ts) // 2]
