@@ -26,7 +26,7 @@
 namespace qsae {
 
 int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
-                       float* tau, uint2* cand, int* cnt, int cap, hipStream_t s);
+                       float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s);
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
@@ -210,12 +210,29 @@ select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         }
     }
     const int nslots = (n + 63) / 64;             // wave-uniform
-    unsigned long long T = 0ull;
-    for (int bit = 47; bit >= 0; --bit) {
+    // Bits on which all keys agree need no trial: start below the highest differing bit.
+    unsigned long long all_or = 0ull, all_and = ~0ull;
+    for (int s = 0; s < nslots; ++s) {
+        const bool live = (s * 64 + lane) < n;
+        all_or |= live ? key[s] : 0ull;
+        all_and &= live ? key[s] : ~0ull;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    const unsigned long long differ = (all_or ^ all_and) & 0xFFFFFFFFFFFFull;
+    const int top_bit = differ ? (63 - __clzll(differ)) : -1;
+    unsigned long long T = all_and & ~((top_bit >= 0) ? ((2ull << top_bit) - 1ull) : 0ull);   // common prefix
+    int at_or_above = n;                          // keys >= T
+    // MSB-first bisection; stops as soon as the set {key >= T} has exactly k members (usually well
+    // before the 16 index bits, which only matter when values tie at the boundary)
+    for (int bit = top_bit; bit >= 0; --bit) {
+        if (at_or_above == k) break;            // exactly k keys at or above T: they are the top-k
         const unsigned long long trial = T | (1ull << bit);
         int c = 0;
         for (int s = 0; s < nslots; ++s) c += __popcll(__ballot(key[s] >= trial));
-        if (c >= k) T = trial;
+        if (c >= k) { T = trial; at_or_above = c; }
     }
     // T is the k-th largest key: exactly k keys are >= T.  Compact them, then rank.
     unsigned long long* mine = sel[wave];
@@ -297,14 +314,13 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     int rc = dense_latent(x, W, bias, B, D, P, pilot, P, stream, kperm);
     if (rc != QSAE_OK) return rc;
     const int j = kPilotRank < P ? kPilotRank : P;
-    rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, s);
+    // (the pilot kernel also zero-fills the pilot columns of the dense latent: the sweep only visits h >= P)
+    rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, dense, dense_ld, s);
     if (rc != QSAE_OK) return rc;
     // 2. sweep of the remaining hidden units with the threshold filter (R = W rows, Cm = x rows)
     {
         constexpr int BM = 128, BN = 128, BK = 32;
         using Epi = EpiFilter<BM, BN>;
-        if (dense)   // pilot columns of the dense latent: the sweep only visits hidden units >= P
-            QSAE_HIP(hipMemset2DAsync(dense, static_cast<size_t>(dense_ld) * 4, 0, static_cast<size_t>(P) * 4, B, s));
         typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld};
         const int Hs = H - P;
         hipEvent_t e0 = nullptr, e1 = nullptr;

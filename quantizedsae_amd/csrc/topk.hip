@@ -44,6 +44,8 @@ struct PilotOut {
     uint2* cand;
     int* cnt;
     int cap;
+    float* dense;        // optional: the row's first H (pilot) columns of the dense latent are zero-filled
+    int64_t dense_ld;    //   here, on the way (the sweep zero-fills the rest, the survivors are scattered later)
 };
 
 template <int VPT4>
@@ -199,6 +201,11 @@ topk_rows_kernel(float* __restrict__ latent, int64_t ld, int H, int k, int32_t* 
                 }
             }
         }
+        if (pilot.dense != nullptr) {
+            float* drow = pilot.dense + static_cast<int64_t>(blockIdx.x) * pilot.dense_ld;
+            for (int e = tid * 4; e < H; e += kTopkThreads * 4)
+                *reinterpret_cast<f32x4*>(drow + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
         if (tid == 0) pilot.cnt[blockIdx.x] = sh.count;
         return;
@@ -236,8 +243,8 @@ static int launch_topk(float* latent, int64_t ld, int B, int H, int k, int32_t* 
 
 // shared by qsae_topk_rows and the pilot stage of qsae_encode_topk (encode_topk.hip)
 int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
-                       float* tau, uint2* cand, int* cnt, int cap, hipStream_t s) {
-    const PilotOut pilot{tau, cand, cnt, cap};
+                       float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s) {
+    const PilotOut pilot{tau, cand, cnt, cap, dense, dense_ld};
     const int per_thread4 = (H + 1023) / 1024;
     if (per_thread4 <= 1) return launch_topk<1>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
     if (per_thread4 <= 2) return launch_topk<2>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
@@ -262,6 +269,6 @@ extern "C" int qsae_topk_rows(float* latent, int64_t ld, int B, int H, int k, in
     QSAE_CHECK_SUPPORTED(H <= 32768, "H <= 32768");
     QSAE_CHECK_SUPPORTED(H % 4 == 0 && ld % 4 == 0, "H and ld must be multiples of 4");
     QSAE_CHECK_ARG(aligned16(latent), "latent must be 16-byte aligned");
-    return topk_rows_dispatch(latent, ld, B, H, k, idx, val, zero_rest, nullptr, nullptr, nullptr, 0,
+    return topk_rows_dispatch(latent, ld, B, H, k, idx, val, zero_rest, nullptr, nullptr, nullptr, 0, nullptr, 0,
                               as_stream(stream));
 }
