@@ -35,6 +35,22 @@ BYTES_PER_ROW_DENSE = 4 * D + 4 * H + 4 * D             # 135 168 B per row, den
 PEAK_FP32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, chip-level parameters
 
 
+def pmc_traffic(fused: bool):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
+    command, FETCH_SIZE doubled per the gfx950 correction).  bench.py cannot profile itself; the
+    number is quoted only for the kernel/shape it was collected on, otherwise null."""
+    try:
+        doc = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
+        if fused:
+            for name, rec in doc["kernels"].items():
+                if name.startswith("sweep_dma"):
+                    return rec["hbm_side_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def build_model(device, seed=1):
     """BinarySAE(512, 32768, gamma=4, n_bits=4): xavier-uniform encoder, zero biases, saturated
     +-30 decoder logits with fair random bits, torch generator on device."""
@@ -188,7 +204,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
-                         "avg_kernel_ms": enc_ms, "traffic": None},
+                         "avg_kernel_ms": enc_ms, "traffic": pmc_traffic(bool(sweep_n))},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
