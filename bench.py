@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=4096)
-    ap.add_argument("--latent-path", default="auto", choices=["auto", "fused", "inplace"])
+    ap.add_argument("--latent-path", default="auto", choices=["auto", "fused", "inplace", "prefilter"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

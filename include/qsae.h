@@ -107,6 +107,23 @@ int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, i
                             int32_t* idx, float* val, float* dense, int64_t dense_ld, int kperm,
                             void* workspace, size_t workspace_bytes, qsae_stream_t stream);
 
+/* Order-preserving fp16 prefilter for the same operation.  A fp16 MFMA pass (per-row power-of-two
+ * scaling, fp32 accumulation) with a rigorous per-row error bound eps_b only decides which hidden units
+ * CAN belong to a row's top-k (everything with approximate value >= approximate k-th - 2 eps_b, ~90 of
+ * 32768); those survivors are re-evaluated with the exact fp32 fmaf chain and ranked exactly, so idx,
+ * val and dense are bit-identical to qsae_encode_topk_latent.  Rows the bound cannot serve (non-finite
+ * inputs, overflowing lists) go through the exact kernels.  Wq/meta come from qsae_prefilter_pack_w
+ * (once per checkpoint: Wq = H*D fp16, meta = 4 device floats).  D % 64 == 0, D <= 2048; other shapes
+ * return QSAE_ERR_UNSUPPORTED (use qsae_encode_topk_latent).  dense may be NULL. */
+size_t qsae_prefilter_w_bytes(int H, int D);
+int qsae_prefilter_pack_w(const float* W, const float* bias, int H, int D, void* Wq, float* meta,
+                          qsae_stream_t stream);
+size_t qsae_encode_topk_prefilter_workspace_bytes(int B, int D, int H, int k);
+int qsae_encode_topk_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                               const float* meta, int B, int D, int H, int k, int32_t* idx, float* val,
+                               float* dense, int64_t dense_ld, void* workspace, size_t workspace_bytes,
+                               qsae_stream_t stream);
+
 /* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
 int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
                  qsae_stream_t stream);

@@ -26,7 +26,8 @@
 namespace qsae {
 
 int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
-                       float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s);
+                       float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s,
+                       const float* margin = nullptr);
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
@@ -79,7 +80,9 @@ static FusedLayout fused_layout(int B, int D, int H, int k) {
 }
 
 // ---- sweep epilogue: threshold filter ---------------------------------------------------------
-template <int BM, int BN, int WMW = 2, int WNW = 2>
+// APPROX (fp16 prefilter): the accumulator holds the scaled fp16 contraction; the value compared and
+// stored is fma(acc, inv[row], bias[h]) and the row threshold is tau[row] - margin[row].
+template <int BM, int BN, int WMW = 2, int WNW = 2, bool APPROX = false>
 struct EpiFilter {
     static constexpr int WTM = BM / WMW, WTN = BN / WNW, MT = WTM / 32, NT = WTN / 32;
     static constexpr int kThreads = 64 * WMW * WNW;
@@ -95,8 +98,11 @@ struct EpiFilter {
         int hidden_offset;   // index of the first swept hidden unit
         float* dense;        // optional [B][dense_ld]: the tile's block of the dense latent is zero-filled
         int64_t dense_ld;    //   here (the k survivors are scattered in afterwards); nullptr = no dense output
+        const float* inv;    // APPROX: [B] 1 / (row scale * weight scale), a power of two
+        const float* margin; // APPROX: [B] 2 * eps_b
     };
     float tau[NT];
+    float inv[NT];
     bool col_ok[NT];
 
     __device__ __forceinline__ void begin(const Args& a, const TileCtx& c) {
@@ -110,6 +116,11 @@ struct EpiFilter {
             const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
             col_ok[nt] = col < c.N;
             tau[nt] = col_ok[nt] ? a.tau[col] : __builtin_huge_valf();
+            inv[nt] = 1.0f;
+            if (APPROX && col_ok[nt]) {
+                tau[nt] = tau[nt] - a.margin[col];
+                inv[nt] = a.inv[col];
+            }
         }
         // visibility of the counters: the kernel's first __syncthreads() follows begin()
     }
@@ -120,7 +131,7 @@ struct EpiFilter {
             for (int r = 0; r < 16; ++r) {
                 int h = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
                 h = h < c.M ? h : c.M - 1;
-                const float b = a.bias ? a.bias[h] : 0.0f;
+                const float b = (!APPROX && a.bias) ? a.bias[h] : 0.0f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = b;
             }
@@ -144,6 +155,17 @@ struct EpiFilter {
                     *reinterpret_cast<f32x4*>(a.dense + static_cast<int64_t>(row) * a.dense_ld + h0 + cc) = z;
             }
         }
+        float hb[MT][16];   // APPROX: bias of the hidden unit behind each accumulator register
+        if (APPROX) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int h = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                    h = h < c.M ? h : c.M - 1;
+                    hb[mt][r] = a.bias ? a.bias[h] : 0.0f;
+                }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int lcol = c.wn * WTN + nt * 32 + c.lane_col;
@@ -153,7 +175,7 @@ struct EpiFilter {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[mt][nt][r];
+                    const float v = APPROX ? fmaf(acc[mt][nt][r], inv[nt], hb[mt][r]) : acc[mt][nt][r];
                     if (!(v < t)) {      // v >= tau, or NaN (which ranks above everything)
                         const int h = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
                         if (h < c.M && col_ok[nt]) {
@@ -299,6 +321,40 @@ static int run_chunked(const float* x, const float* W, const float* bias, int B,
     return QSAE_OK;
 }
 
+// Flagged rows (tau not a valid lower bound, overflowing list, non-finite inputs): normally none.  One
+// 4-byte read-back, then the unfused exact kernels on exactly those rows.
+static int run_flagged_rows(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
+                            int32_t* idx, float* val, char* ws, const FusedLayout& L, qsae_stream_t stream,
+                            bool kperm) {
+    hipStream_t s = as_stream(stream);
+    int* flags = reinterpret_cast<int*>(ws + L.flags);
+    int nflag = 0;
+    QSAE_HIP(hipMemcpyAsync(&nflag, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipStreamSynchronize(s));
+    if (nflag <= 0) return QSAE_OK;
+    float* fx = reinterpret_cast<float*>(ws + L.fx);
+    float* flat = reinterpret_cast<float*>(ws + L.flat);
+    int32_t* fidx = reinterpret_cast<int32_t*>(ws + L.fidx);
+    float* fval = reinterpret_cast<float*>(ws + L.fval);
+    for (int f0 = 0; f0 < nflag; f0 += kChunkRows) {
+        const int n = (nflag - f0) < kChunkRows ? (nflag - f0) : kChunkRows;
+        const int* rows = flags + 1 + f0;
+        const long long tot = static_cast<long long>(n) * D;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows, n,
+                           D, fx);
+        QSAE_LAUNCH_CHECK();
+        int rc = dense_latent(fx, W, bias, n, D, H, flat, H, stream, kperm);
+        if (rc != QSAE_OK) return rc;
+        rc = qsae_topk_rows(flat, H, n, H, k, fidx, fval, 0, stream);
+        if (rc != QSAE_OK) return rc;
+        const long long tk = static_cast<long long>(n) * k;
+        hipLaunchKernelGGL(scatter_topk_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx, fval,
+                           rows, n, k, idx, val);
+        QSAE_LAUNCH_CHECK();
+    }
+    return QSAE_OK;
+}
+
 static int run_fused(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
                      float* val, char* ws, qsae_stream_t stream, bool kperm, float* dense, int64_t dense_ld) {
     hipStream_t s = as_stream(stream);
@@ -321,7 +377,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     {
         constexpr int BM = 128, BN = 128, BK = 32;
         using Epi = EpiFilter<BM, BN>;
-        typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld};
+        typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, nullptr, nullptr};
         const int Hs = H - P;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_time_sweep) {
@@ -331,7 +387,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
         }
         if (kperm && g_sweep_kernel == 0 && D % kDmaBK == 0) {
             using EpiD = EpiFilter<256, 128, 4, 2>;
-            typename EpiD::Args ed{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld};
+            typename EpiD::Args ed{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, nullptr, nullptr};
             rc = launch_gemm_dma<EpiD, 256, 128>(W + static_cast<size_t>(P) * D, Hs, x, B, D, ed, s);
         } else if (kperm) {
             using LA = LoaderF32<BM, BK, false, true, true>;
@@ -363,31 +419,352 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
                        kCandCap, B, H, k, idx, val, flags);
     QSAE_LAUNCH_CHECK();
     // 4. flagged rows (normally none): one 4-byte read-back, then the unfused kernels on those rows
-    int nflag = 0;
-    QSAE_HIP(hipMemcpyAsync(&nflag, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    QSAE_HIP(hipStreamSynchronize(s));
-    if (nflag > 0) {
-        float* fx = reinterpret_cast<float*>(ws + L.fx);
-        float* flat = reinterpret_cast<float*>(ws + L.flat);
-        int32_t* fidx = reinterpret_cast<int32_t*>(ws + L.fidx);
-        float* fval = reinterpret_cast<float*>(ws + L.fval);
-        for (int f0 = 0; f0 < nflag; f0 += kChunkRows) {
-            const int n = (nflag - f0) < kChunkRows ? (nflag - f0) : kChunkRows;
-            const int* rows = flags + 1 + f0;
-            const long long tot = static_cast<long long>(n) * D;
-            hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows,
-                               n, D, fx);
-            QSAE_LAUNCH_CHECK();
-            rc = dense_latent(fx, W, bias, n, D, H, flat, H, stream, kperm);
-            if (rc != QSAE_OK) return rc;
-            rc = qsae_topk_rows(flat, H, n, H, k, fidx, fval, 0, stream);
-            if (rc != QSAE_OK) return rc;
-            const long long tk = static_cast<long long>(n) * k;
-            hipLaunchKernelGGL(scatter_topk_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx,
-                               fval, rows, n, k, idx, val);
-            QSAE_LAUNCH_CHECK();
+    rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, kperm);
+    if (rc != QSAE_OK) return rc;
+    if (dense) return scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
+    return QSAE_OK;
+}
+
+// =====================================================================================================
+// fp16 prefilter: an order-preserving approximation decides WHICH hidden units can be in a row's top-k;
+// every returned value and the final selection are exact fp32.
+//
+//   s^_bh = bias_h + (sum_k fp16(x_bk * sx_b) * fp16(W_hk * sw)) / (sx_b * sw)        (fp16 MFMA, fp32 accumulate)
+//   |s^_bh - s_bh| <= eps_b   for the exact fmaf chain s_bh, with
+//   eps_b = c1 * ||x_b||_2 * max_h ||W_h||_2 + small absolute terms,   c1 = 1.25e-3 >=
+//       2^-10 (1 + 2^-11)   two fp16 roundings per product (power-of-two scalings are exact)
+//     + 4 * 512 * 2^-24     fp32 accumulation of the exact fp16 x fp16 products, 4x safety on the unit roundoff
+//     + 512 * 2^-24         the exact chain's own distance from the real-number dot product
+//   (Cauchy-Schwarz bounds sum_k |x_k||w_k|).  If t~ is the k-th largest s^ of a row, every member of the
+//   exact top-k satisfies s^ >= t~ - 2 eps_b; those survivors (~90 of 32768) are re-evaluated with the
+//   exact chain and ranked exactly.  tests/test_kernels_gpu.py measures max|s^ - s| / eps_b on hardware.
+struct PrefLayout {
+    size_t xq, inv, margin, total_extra;
+};
+static PrefLayout pref_layout(int B, int D, size_t base) {
+    PrefLayout P;
+    size_t off = base;
+    P.xq = off;     off = align_up(off + static_cast<size_t>(B) * D * 2, 256);
+    P.inv = off;    off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    P.margin = off; off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    P.total_extra = off;
+    return P;
+}
+
+// meta (device float[4]): [0] sw (power-of-two weight scale), [1] max_h ||W_h||_2, [2] max|bias|, [3] max|W|
+__global__ void __launch_bounds__(256)
+pref_w_stats_kernel(const float* __restrict__ W, const float* __restrict__ bias, int H, int D, unsigned* __restrict__ meta) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= H) return;
+    float mx = 0.f, ss = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float w = W[static_cast<int64_t>(row) * D + d];
+        const float a = fabsf(w);
+        mx = (a > mx || a != a) ? a : mx;       // NaN propagates (a != a)
+        ss = fmaf(w, w, ss);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(mx, off, 64);
+        mx = (o > mx || o != o) ? o : mx;
+        ss += __shfl_xor(ss, off, 64);
+    }
+    if (lane == 0) {
+        const float nrm = sqrtf(ss) * 1.000001f;
+        // non-negative floats (and NaN, which has the largest bit pattern) order like their bit patterns
+        atomicMax(&meta[1], __float_as_uint(nrm));
+        atomicMax(&meta[3], __float_as_uint(mx));
+        if (bias) atomicMax(&meta[2], __float_as_uint(fabsf(bias[row])));
+    }
+}
+
+__device__ __forceinline__ float pow2_scale_for(float maxabs) {
+    // power of two s with maxabs * s in [64, 128); 1 for zero, 0 (unusable) for non-finite input
+    if (!(maxabs == maxabs) || maxabs == __builtin_huge_valf()) return 0.f;
+    if (maxabs == 0.f) return 1.f;
+    int e;
+    (void)frexpf(maxabs, &e);                   // maxabs = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 7 - e);
+}
+
+__global__ void __launch_bounds__(256)
+pref_w_cast_kernel(const float* __restrict__ W, long long n, float* __restrict__ meta, _Float16* __restrict__ Wq) {
+    const float sw = pow2_scale_for(meta[3]);
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid == 0) meta[0] = sw;
+    if (gid < n) Wq[gid] = static_cast<_Float16>(W[gid] * sw);       // exact scaling, one RNE rounding
+}
+
+// one wave per activation row: fp16 copy scaled by a per-row power of two, 1/(sx*sw), margin = 2*eps_b
+__global__ void __launch_bounds__(256)
+pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ meta,
+                   _Float16* __restrict__ xq, float* __restrict__ inv, float* __restrict__ margin) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* xr = x + static_cast<int64_t>(row) * D;
+    float mx = 0.f, ss = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = xr[d];
+        const float a = fabsf(v);
+        mx = (a > mx || a != a) ? a : mx;
+        ss = fmaf(v, v, ss);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(mx, off, 64);
+        mx = (o > mx || o != o) ? o : mx;
+        ss += __shfl_xor(ss, off, 64);
+    }
+    const float sw = meta[0], wn = meta[1], bmax = meta[2];
+    const float sx = pow2_scale_for(mx);
+    for (int d = lane; d < D; d += 64) xq[static_cast<int64_t>(row) * D + d] = static_cast<_Float16>(xr[d] * sx);
+    if (lane == 0) {
+        const float nrm = sqrtf(ss) * 1.000001f;
+        float eps = __builtin_huge_valf();            // non-finite row or weights: everything is a candidate -> flagged
+        float iv = 0.f;
+        if (sx > 0.f && sw > 0.f && nrm < 3.0e38f && wn < 3.0e38f) {
+            const float sd = sqrtf(static_cast<float>(D));
+            eps = 1.25e-3f * nrm * wn                                   // relative part (see header)
+                  + 2.4e-7f * (nrm * wn + bmax)                         // final scale/bias roundings
+                  + 6.0e-8f * sd * (wn / sx + nrm / sw);                // fp16 subnormal flushing of tiny elements
+            eps *= 1.0001f;
+            iv = (1.0f / sx) * (1.0f / sw);                            // powers of two: exact
+        }
+        inv[row] = iv;
+        margin[row] = 2.0f * eps;
+    }
+}
+
+// pilot epilogue: approximate dense latents of the first P hidden units, rows = activations (registers),
+// columns = hidden units (lanes): out[b][h] = fma(acc, inv[b], bias[h])
+template <int BM, int BN, int WMW, int WNW>
+struct EpiApproxDense {
+    static constexpr int WTM = BM / WMW, WTN = BN / WNW, MT = WTM / 32, NT = WTN / 32;
+    static constexpr int kCheckpoints = 0;
+    static constexpr int kLdsFloats = 0;
+    static constexpr int kStoresPerFinish = 0;
+    struct Args {
+        const float* inv;
+        const float* bias;
+        float* out;
+        int64_t ld;
+    };
+    __device__ __forceinline__ void begin(const Args&, const TileCtx&) {}
+    __device__ __forceinline__ void end(const Args&, const TileCtx&) {}
+    __device__ __forceinline__ void init(const Args&, f32x16 (&acc)[MT][NT], const TileCtx&) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    }
+    __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
+        float bcol[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+            bcol[nt] = (a.bias && col < c.N) ? a.bias[col] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                if (row >= c.M) continue;
+                const float iv = a.inv[row];
+                float* orow = a.out + static_cast<int64_t>(row) * a.ld;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+                    if (col < c.N) orow[col] = fmaf(acc[mt][nt][r], iv, bcol[nt]);
+                }
+            }
+    }
+};
+
+// ---- refine: approximate k-th -> survivors -> exact fp32 chain -> exact top-k; one wave per row --------
+constexpr int kRefWaves = 2;
+constexpr int kRefMaxD = 2048;     // activation row cached in LDS
+constexpr int kRefMaxSurv = 512;   // survivors per row (more -> flagged, exact fallback)
+
+struct RefShared {
+    float x[kRefWaves][kRefMaxD];
+    unsigned long long key[kRefWaves][kRefMaxSurv];
+    int hidx[kRefWaves][kRefMaxSurv];
+};
+
+__global__ void __launch_bounds__(64 * kRefWaves)
+refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
+                   const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
+                   float* __restrict__ val_out, int* __restrict__ flags) {
+    __shared__ RefShared sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * kRefWaves + wave;
+    if (b >= B) return;
+    auto flag_row = [&]() {
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+    };
+    const int n = cnt[b];
+    if (n < k || n > cap) { flag_row(); return; }
+    // ---- approximate k-th largest (same MSB-first bisection as select_topk_kernel) -----------------
+    unsigned long long key[kSelSlots];
+    float aval[kSelSlots];
+    const uint2* list = cand + static_cast<int64_t>(b) * cap;
+    const int nslots = (n + 63) / 64;
+#pragma unroll
+    for (int s = 0; s < kSelSlots; ++s) {
+        const int i = s * 64 + lane;
+        key[s] = 0ull;
+        aval[s] = -__builtin_huge_valf();
+        if (s < nslots && i < n) {
+            const uint2 c = list[i];
+            aval[s] = __uint_as_float(c.x);
+            key[s] = (static_cast<unsigned long long>(mono_key(aval[s])) << 16) |
+                     static_cast<unsigned long long>((H - 1) - static_cast<int>(c.y));
         }
     }
+    unsigned long long T = 0ull;
+    int at_or_above = n;
+    for (int bit = 47; bit >= 0; --bit) {
+        if (at_or_above == k) break;
+        const unsigned long long trial = T | (1ull << bit);
+        int c = 0;
+        for (int s = 0; s < nslots; ++s) c += __popcll(__ballot(key[s] >= trial));
+        if (c >= k) { T = trial; at_or_above = c; }
+    }
+    // t~ = smallest approximate value inside the approximate top-k
+    float tk = __builtin_huge_valf();
+    bool any_nan = false;
+    for (int s = 0; s < nslots; ++s) {
+        if (key[s] >= T && key[s] != 0ull) {
+            if (aval[s] != aval[s]) any_nan = true; else tk = fminf(tk, aval[s]);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) tk = fminf(tk, __shfl_xor(tk, off, 64));
+    if (__any(any_nan)) { flag_row(); return; }            // NaN latents: let the exact path rank them
+    // the list holds everything >= tau - margin; t~ must not lie below tau or survivors could be missing
+    if (!(tk >= tau[b])) { flag_row(); return; }
+    const float cut = tk - margin[b];
+    // ---- survivors -> LDS ----------------------------------------------------------------------------
+    int* hidx = sh.hidx[wave];
+    int m = 0;
+    for (int s = 0; s < nslots; ++s) {
+        const bool keep = key[s] != 0ull && !(aval[s] < cut);
+        const unsigned long long msk = __ballot(keep);
+        if (keep) {
+            const int pos = m + __popcll(msk & ((1ull << lane) - 1ull));
+            if (pos < kRefMaxSurv) hidx[pos] = (H - 1) - static_cast<int>(key[s] & 0xFFFFull);
+        }
+        m += __popcll(msk);
+    }
+    if (m > kRefMaxSurv) { flag_row(); return; }
+    float* xs = sh.x[wave];
+    for (int d = lane; d < D; d += 64) xs[d] = x[static_cast<int64_t>(b) * D + d];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- exact fp32 chain per survivor (ascending k, seeded with the bias: the oracle's arithmetic) ---
+    unsigned long long* ekey = sh.key[wave];
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < m) {
+            const int h = hidx[j];
+            const f32x4* wr = reinterpret_cast<const f32x4*>(W + static_cast<int64_t>(h) * D);
+            float acc = bias ? bias[h] : 0.0f;
+            for (int i = 0; i < D / 4; ++i) {
+                const f32x4 w = wr[i];
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * i);
+                acc = fmaf(xv[0], w[0], acc);
+                acc = fmaf(xv[1], w[1], acc);
+                acc = fmaf(xv[2], w[2], acc);
+                acc = fmaf(xv[3], w[3], acc);
+            }
+            ekey[j] = full_key(acc, static_cast<uint32_t>(h));
+            // keep the exact bits next to the key (NaN payloads / -0 are not recoverable from the key)
+            reinterpret_cast<float*>(hidx)[j] = acc;     // hidx[j] is consumed; reuse the slot for the value
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- exact rank among the survivors ----------------------------------------------------------------
+    for (int j = lane; j < m; j += 64) {
+        const unsigned long long mine = ekey[j];
+        int rank = 0;
+        for (int i = 0; i < m; ++i) rank += (ekey[i] > mine) ? 1 : 0;
+        if (rank < k) {
+            idx_out[static_cast<int64_t>(b) * k + rank] = static_cast<int32_t>(key_index(mine));
+            val_out[static_cast<int64_t>(b) * k + rank] = reinterpret_cast<const float*>(hidx)[j];
+        }
+    }
+}
+
+static bool prefilter_shape_ok(int B, int D, int H, int k) {
+    return use_fused(B, D, H, k) && D % 64 == 0 && D <= kRefMaxD && (H - pilot_width(H)) > 0;
+}
+
+static int run_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
+                         int B, int D, int H, int k, int32_t* idx, float* val, char* ws, qsae_stream_t stream,
+                         float* dense, int64_t dense_ld) {
+    hipStream_t s = as_stream(stream);
+    const FusedLayout L = fused_layout(B, D, H, k);
+    const PrefLayout PL = pref_layout(B, D, L.total);
+    const int P = pilot_width(H);
+    float* pilot = reinterpret_cast<float*>(ws + L.pilot);
+    float* tau = reinterpret_cast<float*>(ws + L.tau);
+    int* cnt = reinterpret_cast<int*>(ws + L.cnt);
+    uint2* cand = reinterpret_cast<uint2*>(ws + L.cand);
+    int* flags = reinterpret_cast<int*>(ws + L.flags);
+    _Float16* xq = reinterpret_cast<_Float16*>(ws + PL.xq);
+    float* inv = reinterpret_cast<float*>(ws + PL.inv);
+    float* margin = reinterpret_cast<float*>(ws + PL.margin);
+    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+    // 1. fp16 copy of the batch + per-row scale and error margin
+    hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
+    QSAE_LAUNCH_CHECK();
+    const int Kw = D / 2;                                    // 4-byte words per fp16 row
+    const float* xq_w = reinterpret_cast<const float*>(xq);
+    const float* wq_w = reinterpret_cast<const float*>(Wq);
+    // 2. approximate pilot block [B][P] (activation rows on registers, hidden units on lanes)
+    {
+        using EpiP = EpiApproxDense<256, 128, 4, 2>;
+        typename EpiP::Args ep{inv, bias, pilot, P};
+        int rc = launch_gemm_dma<EpiP, 256, 128, true>(xq_w, B, wq_w, P, Kw, ep, s, /*sweep=*/8);
+        if (rc != QSAE_OK) return rc;
+    }
+    // 3. tau~ = j-th largest approximate pilot value; seeds = pilot elements >= tau~ - 2 eps
+    const int j = kPilotRank < P ? kPilotRank : P;
+    int rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, dense, dense_ld, s,
+                                margin);
+    if (rc != QSAE_OK) return rc;
+    // 4. fp16 sweep of the remaining hidden units with the threshold filter (tau~ - 2 eps)
+    {
+        using EpiS = EpiFilter<256, 128, 4, 2, true>;
+        typename EpiS::Args es{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, inv, margin};
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_time_sweep) {
+            QSAE_HIP(hipEventCreate(&e0));
+            QSAE_HIP(hipEventCreate(&e1));
+            QSAE_HIP(hipEventRecord(e0, s));
+        }
+        rc = launch_gemm_dma<EpiS, 256, 128, true>(wq_w + static_cast<size_t>(P) * Kw, H - P, xq_w, B, Kw, es, s);
+        if (g_time_sweep) {
+            QSAE_HIP(hipEventRecord(e1, s));
+            g_sweep_events.emplace_back(e0, e1);
+        }
+        if (rc != QSAE_OK) return rc;
+    }
+    // 5. survivors -> exact chain -> exact top-k
+    hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), 0, s, cand, cnt,
+                       kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags);
+    QSAE_LAUNCH_CHECK();
+    // 6. flagged rows through the exact unfused kernels
+    rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false);
+    if (rc != QSAE_OK) return rc;
     if (dense) return scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
 }
@@ -482,4 +859,57 @@ extern "C" int qsae_encode_topk_kperm(const float* xp, const float* Wp, const fl
                                       qsae_stream_t stream) {
     if (D % 32 != 0) return fail(QSAE_ERR_UNSUPPORTED, "%s: K-interleaved operands need D %% 32 == 0", __func__);
     return encode_topk_impl(xp, Wp, bias, B, D, H, k, idx, val, workspace, workspace_bytes, stream, true);
+}
+
+// ---- fp16 prefilter entry points ---------------------------------------------------------------------
+extern "C" size_t qsae_prefilter_w_bytes(int H, int D) {
+    return (H > 0 && D > 0) ? static_cast<size_t>(H) * D * 2 : 0;
+}
+
+extern "C" int qsae_prefilter_pack_w(const float* W, const float* bias, int H, int D, void* Wq, float* meta,
+                                     qsae_stream_t stream) {
+    QSAE_CHECK_ARG(H > 0 && D > 0 && W && Wq && meta, "H > 0, D > 0, non-null pointers");
+    hipStream_t s = as_stream(stream);
+    QSAE_HIP(hipMemsetAsync(meta, 0, 4 * sizeof(float), s));
+    hipLaunchKernelGGL(pref_w_stats_kernel, dim3((H + 3) / 4), dim3(256), 0, s, W, bias, H, D,
+                       reinterpret_cast<unsigned*>(meta));
+    QSAE_LAUNCH_CHECK();
+    const long long n = static_cast<long long>(H) * D;
+    hipLaunchKernelGGL(pref_w_cast_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, W, n, meta,
+                       static_cast<_Float16*>(Wq));
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+// test hook: byte offsets of the approximate pilot block [B][P] fp32 and of margin[B] (= 2 eps_b) in the workspace
+extern "C" int qsae_debug_prefilter_offsets(int B, int D, int H, int k, size_t* pilot_off, size_t* margin_off,
+                                            int* pilot_cols) {
+    const FusedLayout L = fused_layout(B, D, H, k);
+    const PrefLayout PL = pref_layout(B, D, L.total);
+    if (pilot_off) *pilot_off = L.pilot;
+    if (margin_off) *margin_off = PL.margin;
+    if (pilot_cols) *pilot_cols = pilot_width(H);
+    return QSAE_OK;
+}
+
+extern "C" size_t qsae_encode_topk_prefilter_workspace_bytes(int B, int D, int H, int k) {
+    if (B <= 0 || H <= 0 || D <= 0 || k <= 0 || !prefilter_shape_ok(B, D, H, k)) return 0;
+    return pref_layout(B, D, fused_layout(B, D, H, k).total).total_extra;
+}
+
+extern "C" int qsae_encode_topk_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                                          const float* meta, int B, int D, int H, int k, int32_t* idx, float* val,
+                                          float* dense, int64_t dense_ld, void* workspace, size_t workspace_bytes,
+                                          qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(x && W && Wq && meta && idx && val && workspace, "null pointer");
+    QSAE_CHECK_ARG(k >= 1 && k <= H, "1 <= k <= H required");
+    QSAE_CHECK_SUPPORTED(prefilter_shape_ok(B, D, H, k), "shape outside the prefilter's range (use qsae_encode_topk)");
+    if (workspace_bytes < qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
+        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", __func__);
+    QSAE_CHECK_ARG(aligned16(workspace) && aligned16(x) && aligned16(W) && aligned16(Wq), "16-byte alignment");
+    if (dense) QSAE_CHECK_ARG(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense), "dense latent alignment / ld");
+    return run_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, k, idx, val,
+                         static_cast<char*>(workspace), stream, dense, dense_ld);
 }

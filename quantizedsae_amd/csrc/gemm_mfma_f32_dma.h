@@ -16,20 +16,29 @@
 //     lane-linearly); the 16-byte chunk j of row r sits at position j ^ (r & 7).  The XOR is applied
 //     on the per-lane SOURCE address of the DMA and again on the fragment read (cdna guide rule 21),
 //     which leaves the ds_read_b128 fragment reads 2-way conflicted instead of 8-way.
+//
+// HALF = true instantiates the same pipeline over fp16 operands ([rows][K] _Float16, natural k order)
+// with v_mfma_f32_32x32x16_f16: a K step is still 128 bytes per row (64 k), the image and the swizzle
+// are unchanged, one 16-byte fragment read feeds one MFMA instead of four.  It is used only as the
+// order-preserving *prefilter* of the encoder+top-k path (encode_topk.hip), never for returned values.
 #pragma once
 
 #include "gemm_mfma_f32.h"
 
 namespace qsae {
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int kDmaThreads = 512;
-constexpr int kDmaBK = 32;
+constexpr int kDmaBK = 32;          // fp32 elements per step (128 bytes per row); fp16: 64 elements
 constexpr int kDmaStages = 3;
 
-template <class Epi, int BM, int BN>
+template <class Epi, int BM, int BN, bool HALF = false>
 __global__ void __launch_bounds__(kDmaThreads, 2)
 gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restrict__ Cp, int N, int K,
                        typename Epi::Args ea, SweepMap map) {
+    // K and the operand pointers are expressed in 4-byte words: an fp16 operand with K16 elements per row
+    // is passed as K = K16 / 2 words per row (so that all addressing below is type-agnostic).
     constexpr int WMW = 4, WNW = 2;                      // wave grid
     constexpr int WTM = BM / WMW, WTN = BN / WNW;        // 64 x 64 per wave
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -136,13 +145,22 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 bf[nt] = *reinterpret_cast<const f32x4*>(sbase + brow + nt * 32 * kDmaBK + choff[g]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+            if (HALF) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, af[mt]), __builtin_bit_cast(f16x8, bf[nt]), acc[mt][nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][t], bf[nt][t], acc[mt][nt], 0, 0, 0);
+            }
         }
         // retire the stage of step s+1 (its DMA was issued during step s-1): everything but the pieces
         // issued at the top of this step must have landed, for every wave, before anyone reads it
@@ -159,10 +177,11 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
     epi.end(ea, ctx);
 }
 
-template <class Epi, int BM, int BN>
+// K is in 4-byte words per row (fp16 operands: elements / 2).  sweep <= 0: a workgroup sweeps every R tile.
+template <class Epi, int BM, int BN, bool HALF = false>
 inline int launch_gemm_dma(const float* Rp, int M, const float* Cp, int N, int K, const typename Epi::Args& ea,
-                           hipStream_t stream) {
-    auto kern = gemm_nt_f32_dma_kernel<Epi, BM, BN>;
+                           hipStream_t stream, int sweep = 0) {
+    auto kern = gemm_nt_f32_dma_kernel<Epi, BM, BN, HALF>;
     constexpr size_t lds = (static_cast<size_t>(kDmaStages) * (BM + BN) * kDmaBK + Epi::kLdsFloats) * sizeof(float);
     static bool configured = false;
     if (!configured) {
@@ -170,14 +189,15 @@ inline int launch_gemm_dma(const float* Rp, int M, const float* Cp, int N, int K
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         configured = true;
     }
-    if (K % kDmaBK != 0) return fail(QSAE_ERR_UNSUPPORTED, "%s: K must be a multiple of 32", __func__);
+    if (K % kDmaBK != 0) return fail(QSAE_ERR_UNSUPPORTED, "%s: K must be a multiple of 32 words", __func__);
     SweepMap map;
     map.tiles_m = (M + BM - 1) / BM;
     map.tiles_n = (N + BN - 1) / BN;
-    map.sweep = map.tiles_m;          // a workgroup sees whole latent rows
-    map.msplit = 1;
+    map.sweep = (sweep <= 0 || sweep > map.tiles_m) ? map.tiles_m : sweep;
+    map.msplit = (map.tiles_m + map.sweep - 1) / map.sweep;
     map.stagger = 0;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(map.tiles_n)), dim3(kDmaThreads), lds, stream, Rp, M, Cp, N,
+    const long long nblocks = static_cast<long long>(map.tiles_n) * map.msplit;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblocks)), dim3(kDmaThreads), lds, stream, Rp, M, Cp, N,
                        K, ea, map);
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;

@@ -185,6 +185,41 @@ def encode_topk_latent(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Te
     return idx, val, dense
 
 
+def prefilter_pack_w(W: torch.Tensor, bias: Optional[torch.Tensor]):
+    """-> (Wq fp16 [H, D], meta fp32 [4]) for encode_topk_prefilter (once per checkpoint)."""
+    W = _f32c(W, "W")
+    H, D = W.shape
+    b = _f32c(bias, "bias") if bias is not None else None
+    Wq = torch.empty((H, D), dtype=torch.float16, device=W.device)
+    meta = torch.zeros((4,), dtype=torch.float32, device=W.device)
+    check(_lib.load().qsae_prefilter_pack_w(_p(W), _p(b), H, D, _p(Wq), _p(meta), _stream()))
+    return Wq, meta
+
+
+def prefilter_supported(B: int, D: int, H: int, k: int) -> bool:
+    return int(_lib.load().qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k)) > 0
+
+
+def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                          meta: torch.Tensor, k: int, want_dense: bool = True):
+    """fp16-prefiltered encoder + exact top-k (+ dense latent): results identical to encode_topk_latent."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    lib = _lib.load()
+    need = int(lib.qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
+    if need == 0:
+        raise ValueError("shape not supported by the fp16 prefilter")
+    ws = _workspace(x.device, need)
+    idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=x.device)
+    dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
+    check(lib.qsae_encode_topk_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(idx), _p(val),
+                                         _p(dense), H, _p(ws), ws.numel(), _stream()))
+    return idx, val, dense
+
+
 def densify(idx: torch.Tensor, val: torch.Tensor, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(idx, "idx", torch.int32)
     _dev(val, "val", torch.float32)

@@ -115,10 +115,21 @@ class BinarySAE(SparseAutoencoder):
             idx, val = ops.encode_topk(xp, Wp, lin.bias, self.top_k, kperm=kperm)
             return idx, val, self.decoder.decode_sparse(idx, val)
 
-    #: "auto" | "fused" | "inplace".  fused: encoder+top-k without a dense latent in HBM, the dense
-    #: [B,H] return value is then a memset + scatter; inplace: dense contraction, top-k masks it in
-    #: place.  Both give bit-identical outputs; auto takes fused for large batches.
+    #: "auto" | "fused" | "inplace" | "prefilter".  fused: exact-fp32 encoder+top-k without a dense
+    #: latent in HBM (the dense [B,H] return value is zero-filled inside the sweep); inplace: dense
+    #: contraction, top-k masks it in place; prefilter: an fp16 MFMA pass with a rigorous error bound
+    #: picks ~90 candidates per row, which are re-evaluated and ranked in exact fp32.  All paths return
+    #: bit-identical outputs; auto takes fused for large batches.
     latent_path = "auto"
+
+    def _prefilter_weights(self):
+        lin = self.encoder.linear
+        if not hasattr(self, "_pref_cache"):
+            self._pref_cache = PackedCache()
+        def build():
+            Wq, meta = ops.prefilter_pack_w(lin.weight.detach(), lin.bias.detach())
+            return {"Wq": Wq, "meta": meta}
+        return self._pref_cache.get((lin.weight, lin.bias), build)
 
     def forward(self, x):
         with torch.no_grad():
@@ -127,13 +138,21 @@ class BinarySAE(SparseAutoencoder):
             path = self.latent_path
             if path == "auto":
                 path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
+            if path == "prefilter":
+                if not ops.prefilter_supported(x.shape[0], self.input_dim, self.hidden_dim, self.top_k):
+                    path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
+                else:
+                    pw = self._prefilter_weights()
+                    xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                    idx, val, latent = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"],
+                                                                 pw["meta"], self.top_k)
             if path == "fused":
                 xp, Wp, kperm = self.encoder.operands(x)
                 idx, val, latent = ops.encode_topk_latent(xp, Wp, lin.bias, self.top_k, kperm=kperm)
             elif path == "inplace":
                 latent = self.encoder(x)
                 idx, val = ops.topk_rows(latent, self.top_k, zero_rest=True)     # latent * mask, in place
-            else:
-                raise ValueError(f"latent_path must be 'auto', 'fused' or 'inplace', got {path!r}")
+            elif path != "prefilter":
+                raise ValueError(f"latent_path must be 'auto', 'fused', 'inplace' or 'prefilter', got {path!r}")
             recon = self.decoder.decode_sparse(idx, val)
             return latent, recon, self.decoder.packed()["polarize"]

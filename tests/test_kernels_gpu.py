@@ -403,3 +403,76 @@ def test_encode_topk_latent_dense_output(fused_path, B, D, H, k, kperm):
     idx, val, dense = ops.encode_topk_latent(a_x, a_W, dev(bias), k, kperm=kperm)
     assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)
     assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
+
+
+# ---- fp16 prefilter: exact results through an approximate candidate pass ---------------------------------
+def _prefilter(ops, x, W, bias, k, want_dense=True):
+    Wq, meta = ops.prefilter_pack_w(dev(W), dev(bias) if bias is not None else None)
+    return ops.encode_topk_prefilter(dev(x), dev(W), dev(bias) if bias is not None else None, Wq, meta, k,
+                                     want_dense=want_dense)
+
+
+@pytest.mark.parametrize("B,D,H,k", [(1000, 512, 8192, 65), (300, 64, 4096, 8), (2100, 512, 32768, 65)])
+def test_prefilter_equals_oracle(fused_path, B, D, H, k):
+    ops = _ops()
+    x = S.activations(95, B, D)
+    W = S.xavier_uniform(95, H, D, stream=1)
+    bias = S.normal(95, (H,), stream=3, std=0.05)
+    assert ops.prefilter_supported(B, D, H, k)
+    idx, val, dense = _prefilter(ops, x, W, bias, k)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
+    idx2, val2, none = _prefilter(ops, x, W, None, k, want_dense=False)
+    w2 = oracle.topk(oracle.encode(x, W, None), k)
+    assert none is None and np.array_equal(host(idx2), w2[0]) and np.array_equal(host(val2), w2[1])
+
+
+def test_prefilter_error_bound_holds_with_margin(fused_path):
+    """max |approx - exact chain| over the pilot block stays far below the eps_b the selection relies on
+    (inputs with outliers, tiny and huge scales)."""
+    from quantizedsae_amd import _lib
+    ops = _ops()
+    B, D, H, k = 600, 512, 8192, 65
+    x = S.activations(96, B, D)
+    x[::7] *= 1e-6
+    x[1::7] *= 3e4
+    x[2::7, ::5] = 0.0
+    x[3::7, 3] = 250.0                                     # single outlier feature
+    W = S.xavier_uniform(96, H, D, stream=1)
+    W[::3] *= 0.01
+    bias = S.normal(96, (H,), stream=3, std=0.5)
+    idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)
+    lib = _lib.load()
+    po, mo, pc = C.c_size_t(), C.c_size_t(), C.c_int()
+    lib.qsae_debug_prefilter_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 2 + [C.POINTER(C.c_int)]
+    lib.qsae_debug_prefilter_offsets(B, D, H, k, C.byref(po), C.byref(mo), C.byref(pc))
+    ws = ops._workspaces[torch.device(DEV)]
+    P = pc.value
+    approx = host(ws[po.value: po.value + B * P * 4].view(torch.float32).reshape(B, P))
+    margin = host(ws[mo.value: mo.value + B * 4].view(torch.float32))
+    exact = oracle.encode(x, W[:P], bias[:P])
+    ratio = np.abs(approx.astype(np.float64) - exact).max(axis=1) / (margin / 2.0)
+    assert np.isfinite(ratio).all()
+    assert ratio.max() < 0.25, ratio.max()                 # >= 4x headroom on hardware
+
+
+def test_prefilter_degenerate_rows_fall_back(fused_path):
+    ops = _ops()
+    B, D, H, k = 260, 64, 4096, 40
+    x = S.activations(97, B, D)
+    W = S.xavier_uniform(97, H, D, stream=1)
+    bias = np.zeros((H,), np.float32)
+    x[3] = 0.0                                             # every latent ties
+    x[10, 5] = np.inf                                      # non-finite rows
+    x[11, 7] = np.nan
+    idx, val, dense = _prefilter(ops, x, W, bias, k)
+    lat = oracle.encode(x, W, bias)
+    want_idx, want_val = oracle.topk(lat, k)
+    ok = np.ones(B, bool); ok[[10, 11]] = False            # inf/NaN rows: compare index sets only where finite
+    assert np.array_equal(host(idx)[ok], want_idx[ok])
+    assert np.array_equal(host(val)[ok], want_val[ok])
+    assert np.array_equal(host(idx)[~ok], want_idx[~ok])   # exact path ranks NaN/inf rows like the oracle
