@@ -33,22 +33,19 @@ FLOPS_PER_ROW_ENCODER = 2 * D * H                       # the dominant kernel (S
 FLOPS_PER_ROW = 2 * D * H + 2 * K_TOP * D               # 33 620 992 algorithmic FLOP per row
 BYTES_PER_ROW_DENSE = 4 * D + 4 * H + 4 * D             # 135 168 B per row, dense-latent return
 PEAK_FP32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP16_MFMA_TFLOPS = 2500.0                          # dense (the ~5 PF headline figure includes 2:1 sparsity)
 
 
-def pmc_traffic(fused: bool):
+def pmc_traffic(key):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
     command, FETCH_SIZE doubled per the gfx950 correction).  bench.py cannot profile itself; the
     number is quoted only for the kernel/shape it was collected on, otherwise null."""
     try:
         doc = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
-        if fused:
-            for name, rec in doc["kernels"].items():
-                if name.startswith("sweep_dma"):
-                    return rec["hbm_side_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        return doc["kernels"][key]["hbm_side_bytes_per_launch"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def build_model(device, seed=1):
@@ -114,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=4096)
     ap.add_argument("--latent-path", default="auto", choices=["auto", "fused", "inplace", "prefilter"])
+    ap.add_argument("--no-fp32-reference", action="store_true", help="skip the extra fp32-only measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,40 +144,73 @@ def main():
         ops.sq_err_sum(recon, x, acc)
         return latent, recon
 
+    def timed_region(n_steps, acc):
+        """barrier + sync, n_steps forwards, sync + barrier; returns elapsed seconds (max over ranks) and
+        the live HIP-event timing of the dominant sweep kernel."""
+        ops.kernel_timer.reset()
+        ops.kernel_timer.enabled = True
+        ops.sweep_timing(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(acc)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        ops.kernel_timer.enabled = False
+        ops.sweep_timing(False)
+        sweep = ops.sweep_timing_collect(H)
+        return sharding.max_over_ranks(dt, device=device), sweep
+
     for _ in range(args.warmup):
         step(torch.zeros((), dtype=torch.float64, device=device))
-    ops.kernel_timer.reset()
-    ops.kernel_timer.enabled = True
-    ops.sweep_timing(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(sq)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ops.kernel_timer.enabled = False
-    ops.sweep_timing(False)
-    sweep_ms, sweep_n, sweep_frac = ops.sweep_timing_collect(H)
-    elapsed = sharding.max_over_ranks(elapsed, device=device)
+    elapsed, (sweep_ms, sweep_n, sweep_frac) = timed_region(args.steps, sq)
     mse = sharding.reduce_mse(sq, args.steps * B * D)
+    path_used = model.resolved_latent_path(B)
+
+    # the exact-fp32-only path, same model and batch, measured separately (not part of `value`)
+    fp32_ref = None
+    if path_used == "prefilter" and not args.no_fp32_reference:
+        model.latent_path = "fused"
+        n_ref = max(3, min(args.steps, 5))
+        step(torch.zeros((), dtype=torch.float64, device=device))
+        sq_ref = torch.zeros((), dtype=torch.float64, device=device)
+        el_ref, (ms_ref, n_sw, fr_ref) = timed_region(n_ref, sq_ref)
+        mse_ref = sharding.reduce_mse(sq_ref, n_ref * B * D)
+        model.latent_path = args.latent_path
+        ach = fr_ref * FLOPS_PER_ROW_ENCODER * B / (ms_ref * 1e-3) / 1e12 if n_sw else None
+        fp32_ref = {"value": world * B * n_ref / el_ref, "unit": "activations/s", "ms_per_step": el_ref / n_ref * 1e3,
+                    "steps": n_ref, "recon_mse": mse_ref,
+                    "note": "latent_path='fused': every latent computed by the exact-fp32 MFMA sweep (no fp16 pass); "
+                            "outputs bit-identical to the default path",
+                    "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_dma_kernel<EpiFilter<256,128,4,2>> (fp32 MFMA sweep)",
+                                 "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": (ach / PEAK_FP32_MFMA_TFLOPS) if ach else None, "avg_kernel_ms": ms_ref,
+                                 "traffic": pmc_traffic("sweep_dma_fp32") if B == ROWS_PER_GPU else None}}
 
     if rank == 0:
         total_rows = world * B * args.steps
         value = total_rows / elapsed
-        # dominant kernel: the exact-fp32 MFMA encoder contraction (the sweep of the fused path covers
-        # the hidden units the pilot did not: 15/16 of the encoder FLOPs in one launch)
-        if sweep_n:
-            enc_ms, frac_flops = sweep_ms, sweep_frac
-            kname = (f"gemm_nt_f32_kernel<..., EpiFilter> (encoder sweep {B}x512 @ 512x{int(round(H * sweep_frac))} "
-                     "with threshold-filter epilogue, fp32 MFMA)")
+        if path_used == "prefilter" and sweep_n:
+            enc_ms, peak = sweep_ms, PEAK_FP16_MFMA_TFLOPS
+            achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
+            kname = (f"gemm_nt_f32_dma_kernel<EpiFilter<256,128,4,2,APPROX>, HALF> (fp16 MFMA prefilter sweep "
+                     f"{B}x512 @ 512x{int(round(H * sweep_frac))}, threshold filter + fused zero-fill of the dense latent)")
+            tkey = "sweep_dma_fp16"
+        elif sweep_n:
+            enc_ms, peak = sweep_ms, PEAK_FP32_MFMA_TFLOPS
+            achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
+            kname = (f"gemm_nt_f32_dma_kernel<EpiFilter<256,128,4,2>> (fp32 MFMA encoder sweep {B}x512 @ "
+                     f"512x{int(round(H * sweep_frac))} with threshold-filter epilogue)")
+            tkey = "sweep_dma_fp32"
         else:
-            enc_ms, frac_flops = ops.kernel_timer.mean_ms("encode_dense"), 1.0
+            enc_ms, peak = ops.kernel_timer.mean_ms("encode_dense"), PEAK_FP32_MFMA_TFLOPS
+            achieved = FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12 if enc_ms else None
             kname = f"gemm_nt_f32_kernel<..., EpiDense> (encoder {B}x512 @ 512x{H}, fp32 MFMA)"
-        achieved = frac_flops * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12 if enc_ms else None
+            tkey = None
         out = {
             "metric": "activations/sec, BinarySAE 512->32768 n_bits=4 forward (dense latent + reconstruction + MSE)",
             "value": value,
@@ -197,14 +228,22 @@ def main():
                                    "reference forward() signature (dense [B,32768] latent, [B,512] reconstruction, "
                                    "polarize loss) + recon-MSE accumulation",
                        "rows_per_gpu": B, "input_dim": D, "hidden_dim": H, "n_bits": N_BITS, "gamma": GAMMA,
-                       "top_k": K_TOP, "parallelism": f"row-sharded x{world}, no data-path collective"},
+                       "top_k": K_TOP, "parallelism": f"row-sharded x{world}, no data-path collective",
+                       "latent_path": path_used,
+                       "precision_note": ("every returned value (latent, reconstruction, MSE) is exact fp32 and bit-identical "
+                                          "to the fp32-only path; with latent_path='prefilter' an fp16 MFMA pass with a rigorous "
+                                          "per-row error bound only selects ~80 candidate hidden units per row, which are then "
+                                          "re-evaluated with the exact fp32 fmaf chain and ranked exactly (DESIGN.md 4.2b)")},
             "recon_mse": mse,
             "whole_path_tflops_per_gpu": value / world * FLOPS_PER_ROW / 1e12,
+            "whole_path_vs_fp32_mfma_roofline": value / world * FLOPS_PER_ROW / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "whole_path_dense_gbps_per_gpu": value / world * BYTES_PER_ROW_DENSE / 1e9,
             "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
-                         "avg_kernel_ms": enc_ms, "traffic": pmc_traffic(bool(sweep_n))},
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (achieved / peak) if achieved else None,
+                         "avg_kernel_ms": enc_ms,
+                         "traffic": pmc_traffic(tkey) if (tkey and B == ROWS_PER_GPU) else None},
+            "fp32_only_path": fp32_ref,
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1

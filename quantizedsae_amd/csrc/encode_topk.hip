@@ -431,11 +431,12 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
 //
 //   s^_bh = bias_h + (sum_k fp16(x_bk * sx_b) * fp16(W_hk * sw)) / (sx_b * sw)        (fp16 MFMA, fp32 accumulate)
 //   |s^_bh - s_bh| <= eps_b   for the exact fmaf chain s_bh, with
-//   eps_b = c1 * ||x_b||_2 * max_h ||W_h||_2 + small absolute terms,   c1 = 1.25e-3 >=
+//   eps_b = c1 * ||x_b||_2 * max_h ||W_h||_2 + (D + 8) 2^-24 max|bias| + tiny absolute terms,  c1 =
 //       2^-10 (1 + 2^-11)   two fp16 roundings per product (power-of-two scalings are exact)
-//     + 4 * 512 * 2^-24     fp32 accumulation of the exact fp16 x fp16 products, 4x safety on the unit roundoff
-//     + 512 * 2^-24         the exact chain's own distance from the real-number dot product
-//   (Cauchy-Schwarz bounds sum_k |x_k||w_k|).  If t~ is the k-th largest s^ of a row, every member of the
+//     + 4 * D * 2^-24       fp32 accumulation of the exact fp16 x fp16 products, 4x safety on the unit roundoff
+//     + D * 2^-24           the exact chain's own distance from the real-number dot product
+//   (Cauchy-Schwarz bounds sum_k |x_k||w_k|; the bias term is there because every step of the exact chain
+//   rounds at the magnitude of its running sum, which starts at the bias).  If t~ is the k-th largest s^ of a row, every member of the
 //   exact top-k satisfies s^ >= t~ - 2 eps_b; those survivors (~90 of 32768) are re-evaluated with the
 //   exact chain and ranked exactly.  tests/test_kernels_gpu.py measures max|s^ - s| / eps_b on hardware.
 struct PrefLayout {
@@ -522,8 +523,11 @@ pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __res
         float iv = 0.f;
         if (sx > 0.f && sw > 0.f && nrm < 3.0e38f && wn < 3.0e38f) {
             const float sd = sqrtf(static_cast<float>(D));
-            eps = 1.25e-3f * nrm * wn                                   // relative part (see header)
-                  + 2.4e-7f * (nrm * wn + bmax)                         // final scale/bias roundings
+            const float u = 5.9604645e-8f;                              // 2^-24
+            const float c1 = 9.78e-4f + 5.0f * D * u;                   // fp16 input roundings + 4x fp32 accumulation + exact chain
+            eps = c1 * nrm * wn                                         // relative to sum_k |x_k||w_k| <= ||x|| ||w||
+                  + (D + 8.0f) * u * bmax                               // every chain step (and the final fma) also rounds at the bias' magnitude
+                  + 8.0f * u * nrm * wn
                   + 6.0e-8f * sd * (wn / sx + nrm / sw);                // fp16 subnormal flushing of tiny elements
             eps *= 1.0001f;
             iv = (1.0f / sx) * (1.0f / sw);                            // powers of two: exact
@@ -583,25 +587,31 @@ struct EpiApproxDense {
 };
 
 // ---- refine: approximate k-th -> survivors -> exact fp32 chain -> exact top-k; one wave per row --------
-constexpr int kRefWaves = 2;
+constexpr int kRefWaves = 4;
 constexpr int kRefMaxD = 2048;     // activation row cached in LDS
 constexpr int kRefMaxSurv = 512;   // survivors per row (more -> flagged, exact fallback)
-
-struct RefShared {
-    float x[kRefWaves][kRefMaxD];
-    unsigned long long key[kRefWaves][kRefMaxSurv];
-    int hidx[kRefWaves][kRefMaxSurv];
-};
+constexpr int kRefTileStride = 36; // floats per transposed-tile row (32 + 4 pad: conflict-free b128 access)
+// dynamic LDS per wave: x row [D] | transposed W tile [64][36] | exact keys [512] u64 | hidden index / value [512]
+static inline size_t ref_lds_per_wave(int D) {
+    return static_cast<size_t>(D) * 4 + 64 * kRefTileStride * 4 + kRefMaxSurv * 8 + kRefMaxSurv * 4;
+}
 
 __global__ void __launch_bounds__(64 * kRefWaves)
 refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
                    const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
                    float* __restrict__ val_out, int* __restrict__ flags) {
-    __shared__ RefShared sh;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * kRefWaves + wave;
     if (b >= B) return;
+    // per-wave carve (every wave works alone: ordering inside a wave comes from the in-order LDS queue)
+    unsigned char* mybase = ref_smem + static_cast<size_t>(wave) * (static_cast<size_t>(D) * 4 + 64 * kRefTileStride * 4 +
+                                                                     kRefMaxSurv * 8 + kRefMaxSurv * 4);
+    unsigned long long* ekey = reinterpret_cast<unsigned long long*>(mybase);
+    float* xs = reinterpret_cast<float*>(mybase + kRefMaxSurv * 8);
+    float* wt = xs + D;
+    int* hidx = reinterpret_cast<int*>(wt + 64 * kRefTileStride);
     auto flag_row = [&]() {
         if (lane == 0) {
             const int slot = atomicAdd(&flags[0], 1);
@@ -650,7 +660,6 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     if (!(tk >= tau[b])) { flag_row(); return; }
     const float cut = tk - margin[b];
     // ---- survivors -> LDS ----------------------------------------------------------------------------
-    int* hidx = sh.hidx[wave];
     int m = 0;
     for (int s = 0; s < nslots; ++s) {
         const bool keep = key[s] != 0ull && !(aval[s] < cut);
@@ -662,27 +671,68 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         m += __popcll(msk);
     }
     if (m > kRefMaxSurv) { flag_row(); return; }
-    float* xs = sh.x[wave];
     for (int d = lane; d < D; d += 64) xs[d] = x[static_cast<int64_t>(b) * D + d];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- exact fp32 chain per survivor (ascending k, seeded with the bias: the oracle's arithmetic) ---
-    unsigned long long* ekey = sh.key[wave];
+    // A chain is sequential in k, so one lane owns one survivor; but 64 lanes walking 64 different W rows
+    // 16 bytes at a time touch 64 cache lines per load.  Instead the wave fetches [64 survivors x 32 k]
+    // blocks line-wise (8 lanes per 128-byte row segment), transposes them through LDS, and every lane
+    // then reads its own row's 32 values from there: each W line is fetched once.
+    const int nblk = D / 32;                                   // D % 64 == 0: even
     for (int j0 = 0; j0 < m; j0 += 64) {
         const int j = j0 + lane;
-        if (j < m) {
-            const int h = hidx[j];
-            const f32x4* wr = reinterpret_cast<const f32x4*>(W + static_cast<int64_t>(h) * D);
-            float acc = bias ? bias[h] : 0.0f;
-            for (int i = 0; i < D / 4; ++i) {
-                const f32x4 w = wr[i];
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 4 * i);
+        const int h = (j < m) ? hidx[j] : hidx[j0];
+        float acc = bias ? bias[h] : 0.0f;
+        // row pointers of the 8 line-loads this lane takes part in: rows 8i + lane/8 of the group
+        const float* rp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int jj = j0 + 8 * i + (lane >> 3);
+            jj = jj < m ? jj : j0;
+            rp[i] = W + static_cast<int64_t>(hidx[jj]) * D + 4 * (lane & 7);
+        }
+        // two staging sets, two blocks in flight
+        f32x4 s0[8], s1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s0[i] = *reinterpret_cast<const f32x4*>(rp[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s1[i] = *reinterpret_cast<const f32x4*>(rp[i] + 32);
+        auto consume = [&](const f32x4 (&st)[8], int t) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = st[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float* mine = wt + lane * kRefTileStride;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(mine + 4 * q);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 32 * t + 4 * q);
                 acc = fmaf(xv[0], w[0], acc);
                 acc = fmaf(xv[1], w[1], acc);
                 acc = fmaf(xv[2], w[2], acc);
                 acc = fmaf(xv[3], w[3], acc);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int t = 0; t < nblk; t += 2) {
+            consume(s0, t);
+            if (t + 2 < nblk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s0[i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + 2));
+            }
+            consume(s1, t + 1);
+            if (t + 3 < nblk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1[i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + 3));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (j < m) {
             ekey[j] = full_key(acc, static_cast<uint32_t>(h));
             // keep the exact bits next to the key (NaN payloads / -0 are not recoverable from the key)
             reinterpret_cast<float*>(hidx)[j] = acc;     // hidx[j] is consumed; reuse the slot for the value
@@ -759,8 +809,17 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         if (rc != QSAE_OK) return rc;
     }
     // 5. survivors -> exact chain -> exact top-k
-    hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), 0, s, cand, cnt,
-                       kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags);
+    {
+        const size_t lds = ref_lds_per_wave(D) * kRefWaves;
+        static bool configured = false;
+        if (!configured) {
+            QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine_topk_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = true;
+        }
+        hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
+                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags);
+    }
     QSAE_LAUNCH_CHECK();
     // 6. flagged rows through the exact unfused kernels
     rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false);

@@ -14,7 +14,9 @@ class BaselineSparseAutoencoder(nn.Module):
         self.encoder = HipEncoder(nn.Linear(input_dim, hidden_dim))   # no ReLU in the reference either
         self.decoder = nn.Linear(hidden_dim, input_dim)
         self.topk = 32
+        self.latent_path = "auto"      # "auto" | "prefilter" | "fused" | "inplace" (see BinarySAE.latent_path)
         self._cache = PackedCache()
+        self._pref_cache = PackedCache()
 
     def _table(self) -> torch.Tensor:
         # decoder.weight is [D, H]; the sparse decode gathers rows of its transpose [H, D]
@@ -26,7 +28,16 @@ class BaselineSparseAutoencoder(nn.Module):
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            if x.shape[0] >= 2048 and lin.weight.shape[0] >= 8192:
+            H = lin.weight.shape[0]
+            big = x.shape[0] >= 2048 and H >= 8192
+            if big and self.latent_path in ("auto", "prefilter") and \
+                    ops.prefilter_supported(x.shape[0], lin.weight.shape[1], H, self.topk):
+                pw = self._pref_cache.get((lin.weight, lin.bias), lambda: dict(zip(
+                    ("Wq", "meta"), ops.prefilter_pack_w(lin.weight.detach(), lin.bias.detach()))))
+                xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                idx, val, h = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
+                                                        self.topk)
+            elif big and self.latent_path != "inplace":
                 xp, Wp, kperm = self.encoder.operands(x)
                 idx, val, h = ops.encode_topk_latent(xp, Wp, lin.bias, self.topk, kperm=kperm)
             else:

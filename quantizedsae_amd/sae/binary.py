@@ -119,8 +119,19 @@ class BinarySAE(SparseAutoencoder):
     #: latent in HBM (the dense [B,H] return value is zero-filled inside the sweep); inplace: dense
     #: contraction, top-k masks it in place; prefilter: an fp16 MFMA pass with a rigorous error bound
     #: picks ~90 candidates per row, which are re-evaluated and ranked in exact fp32.  All paths return
-    #: bit-identical outputs; auto takes fused for large batches.
+    #: bit-identical outputs; auto takes prefilter for large batches (fused where its shape limits do not
+    #: hold) and inplace for small ones.
     latent_path = "auto"
+
+    def resolved_latent_path(self, batch_rows: int) -> str:
+        """Which path forward() takes for a batch of this many rows (after the auto / shape fallbacks)."""
+        path = self.latent_path
+        big = batch_rows >= 2048 and self.hidden_dim >= 8192
+        if path == "auto":
+            path = "prefilter" if big else "inplace"
+        if path == "prefilter" and not ops.prefilter_supported(batch_rows, self.input_dim, self.hidden_dim, self.top_k):
+            path = "fused" if big else "inplace"
+        return path
 
     def _prefilter_weights(self):
         lin = self.encoder.linear
@@ -137,7 +148,7 @@ class BinarySAE(SparseAutoencoder):
             lin = self.encoder.linear
             path = self.latent_path
             if path == "auto":
-                path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
+                path = "prefilter" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"
             if path == "prefilter":
                 if not ops.prefilter_supported(x.shape[0], self.input_dim, self.hidden_dim, self.top_k):
                     path = "fused" if (x.shape[0] >= 2048 and self.hidden_dim >= 8192) else "inplace"

@@ -287,6 +287,16 @@ def test_full_size_properties():
     # decode is linear in val (power-of-two scaling is exact in fp32, bias is zero here)
     r2 = model.decoder.decode_sparse(idx, val * 2)
     assert torch.equal(r2, recon * 2)
+    # every latent path returns bit-identical tensors (fp16 prefilter, exact fp32 fused sweep, in-place)
+    model.latent_path = "fused"
+    lat_f, rec_f, _ = model(x)
+    assert torch.equal(lat_f, latent) and torch.equal(rec_f, recon)
+    del lat_f, rec_f
+    model.latent_path = "inplace"
+    lat_i, rec_i, _ = model(x)
+    assert torch.equal(lat_i, latent) and torch.equal(rec_i, recon)
+    del lat_i, rec_i
+    model.latent_path = "auto"
     # spot-check 64 rows against the CPU oracle
     sel = torch.arange(0, B, B // 64, device=DEV)
     want = oracle.binary_forward(host(x[sel]), host(model.encoder[0].weight), host(model.encoder[0].bias),
