@@ -22,6 +22,7 @@
 
 #include "gemm_mfma_f32.h"
 #include "gemm_mfma_f32_dma.h"
+#include "sweep_xstat_f16.h"
 
 namespace qsae {
 
@@ -37,6 +38,11 @@ constexpr int kFusedMinRows = 2048;
 constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
+static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
+static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
+static int g_xstat_ablate = 0;     // timing experiments only (results are wrong when non-zero)
+static int g_pref_tile = 2;        // fp16 sweep: 2 = activation-stationary kernel (where supported), 0 = 256 x 256 tile
+                                   // (2 stages), 1 = 256 x 128 tile (3 stages)
 
 // Optional HIP-event bracket around the sweep kernel (bench.py's live roofline measurement): events
 // are recorded on the launch stream and only read by qsae_debug_sweep_timing_collect().
@@ -757,6 +763,17 @@ static bool prefilter_shape_ok(int B, int D, int H, int k) {
     return use_fused(B, D, H, k) && D % 64 == 0 && D <= kRefMaxD && (H - pilot_width(H)) > 0;
 }
 
+// dense latent = zeros (the k survivors are scattered in afterwards): one row per workgroup pass, 16-byte
+// stores, consecutive threads -> consecutive chunks
+__global__ void __launch_bounds__(256)
+zero_rows_kernel(float* __restrict__ dense, int64_t ld, int B, int H4) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int row = blockIdx.x; row < B; row += gridDim.x) {
+        f32x4* out = reinterpret_cast<f32x4*>(dense + static_cast<int64_t>(row) * ld);
+        for (int c = threadIdx.x; c < H4; c += 256) out[c] = z;
+    }
+}
+
 static int run_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
                          int B, int D, int H, int k, int32_t* idx, float* val, char* ws, qsae_stream_t stream,
                          float* dense, int64_t dense_ld) {
@@ -773,6 +790,14 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     float* inv = reinterpret_cast<float*>(ws + PL.inv);
     float* margin = reinterpret_cast<float*>(ws + PL.margin);
     QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+    // The fp16 sweep is bound by memory traffic, so the dense latent's zero-fill is cheaper as a
+    // bandwidth-saturating pass of its own than folded into the sweep epilogue (measured 1.25 vs 1.65 ms).
+    const bool xstat = g_pref_tile == 2 && xstat_supported(D, H - P, P) && H % 4 == 0;
+    float* fused_fill = xstat ? nullptr : dense;
+    if (dense && xstat) {
+        hipLaunchKernelGGL(zero_rows_kernel, dim3(B < 16384 ? B : 16384), dim3(256), 0, s, dense, dense_ld, B, H / 4);
+        QSAE_LAUNCH_CHECK();
+    }
     // 1. fp16 copy of the batch + per-row scale and error margin
     hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
     QSAE_LAUNCH_CHECK();
@@ -788,25 +813,38 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     }
     // 3. tau~ = j-th largest approximate pilot value; seeds = pilot elements >= tau~ - 2 eps
     const int j = kPilotRank < P ? kPilotRank : P;
-    int rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, dense, dense_ld, s,
+    int rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, fused_fill, dense_ld, s,
                                 margin);
     if (rc != QSAE_OK) return rc;
     // 4. fp16 sweep of the remaining hidden units with the threshold filter (tau~ - 2 eps)
     {
         using EpiS = EpiFilter<256, 128, 4, 2, true>;
-        typename EpiS::Args es{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, inv, margin};
+        typename EpiS::Args es{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, fused_fill, dense_ld, inv, margin};
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_time_sweep) {
             QSAE_HIP(hipEventCreate(&e0));
             QSAE_HIP(hipEventCreate(&e1));
             QSAE_HIP(hipEventRecord(e0, s));
         }
-        rc = launch_gemm_dma<EpiS, 256, 128, true>(wq_w + static_cast<size_t>(P) * Kw, H - P, xq_w, B, Kw, es, s);
+        if (xstat) {
+            XsArgs xa{xq + 0, Wq + static_cast<size_t>(P) * D, bias ? bias + P : nullptr, tau, margin, inv, cand, cnt,
+                      B, H - P, kCandCap, P, g_xstat_rot, g_xstat_stamps};
+            rc = launch_xstat(D, xa, s, g_xstat_ablate);
+        } else if (g_pref_tile != 1) {
+            // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
+            using EpiW = EpiFilter<256, 256, 4, 2, true>;
+            typename EpiW::Args ew{es.bias, es.tau, es.cand, es.cnt, es.cap, es.hidden_offset, es.dense, es.dense_ld, es.inv,
+                                   es.margin};
+            rc = launch_gemm_dma<EpiW, 256, 256, true, 2>(wq_w + static_cast<size_t>(P) * Kw, H - P, xq_w, B, Kw, ew, s);
+        } else {
+            rc = launch_gemm_dma<EpiS, 256, 128, true>(wq_w + static_cast<size_t>(P) * Kw, H - P, xq_w, B, Kw, es, s);
+        }
         if (g_time_sweep) {
             QSAE_HIP(hipEventRecord(e1, s));
             g_sweep_events.emplace_back(e0, e1);
         }
         if (rc != QSAE_OK) return rc;
+        if (xstat && g_xstat_ablate != 0) return QSAE_OK;    // timing experiment: the lists are not trustworthy
     }
     // 5. survivors -> exact chain -> exact top-k
     {
@@ -856,6 +894,22 @@ extern "C" int qsae_debug_sweep_timing_collect(double* total_ms, int* launches) 
 // fraction of the encoder FLOPs the sweep launch covers (the pilot block takes the rest)
 extern "C" double qsae_debug_sweep_flop_fraction(int H) {
     return static_cast<double>(H - pilot_width(H)) / static_cast<double>(H);
+}
+
+extern "C" int qsae_debug_set_xstat_stamps(void* buf) {
+    g_xstat_stamps = static_cast<unsigned long long*>(buf);
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_set_xstat_rot(int rot) {
+    g_xstat_rot = rot;
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_set_prefilter_tile(int which) {
+    g_xstat_ablate = which >= 10 ? which - 10 : 0;
+    g_pref_tile = which >= 10 ? 2 : which;
+    return QSAE_OK;
 }
 
 extern "C" int qsae_debug_set_sweep_kernel(int which) {

@@ -31,9 +31,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kDmaThreads = 512;
 constexpr int kDmaBK = 32;          // fp32 elements per step (128 bytes per row); fp16: 64 elements
-constexpr int kDmaStages = 3;
+constexpr int kDmaStages = 3;         // default; a 256 x 256 tile fits only two stages (1-deep prefetch)
 
-template <class Epi, int BM, int BN, bool HALF = false>
+template <class Epi, int BM, int BN, bool HALF = false, int STAGES = kDmaStages>
 __global__ void __launch_bounds__(kDmaThreads, 2)
 gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restrict__ Cp, int N, int K,
                        typename Epi::Args ea, SweepMap map) {
@@ -60,7 +60,7 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
     ctx.lane_col = lane & 31;
     ctx.lane_half = lane >> 5;
     ctx.M = M; ctx.N = N; ctx.K = K; ctx.tid = tid;
-    ctx.lds_epi = smem + kDmaStages * STAGE;
+    ctx.lds_epi = smem + STAGES * STAGE;
     ctx.m0 = m_first * BM;
 
     Epi epi;
@@ -101,15 +101,17 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
             typedef __attribute__((address_space(3))) void* lptr_t;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         }
-        ld_stage = (ld_stage + 1 == kDmaStages) ? 0 : ld_stage + 1;
+        ld_stage = (ld_stage + 1 == STAGES) ? 0 : ld_stage + 1;
         if (++ld_kt == nk) {
             ld_kt = 0;
             ++ld_tile;
             set_a_rows(ld_tile * BM);
         }
     };
+    // prefetch distance AHEAD = STAGES - 1 steps: 3 stages -> DMA two steps ahead, 2 stages -> one step ahead
+    constexpr int AHEAD = STAGES - 1;
     issue_dma();
-    if (nsteps > 1) {
+    if (AHEAD == 2 && nsteps > 1) {
         issue_dma();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
     } else {
@@ -134,8 +136,8 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
             ctx.m0 = tile * BM;
             epi.init(ea, acc, ctx);
         }
-        const bool prefetch = (s_idx + 2) < nsteps;
-        if (prefetch) issue_dma();                        // step s+2 -> the stage last read in step s-1
+        const bool prefetch = (s_idx + AHEAD) < nsteps;
+        if (prefetch) issue_dma();                        // step s+AHEAD -> the stage last read in step s-1
 #pragma unroll
         for (int g = 0; g < kDmaBK / 8; ++g) {
             f32x4 af[MT], bf[NT];
@@ -164,10 +166,10 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
         }
         // retire the stage of step s+1 (its DMA was issued during step s-1): everything but the pieces
         // issued at the top of this step must have landed, for every wave, before anyone reads it
-        if (prefetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        if (prefetch && AHEAD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        st = (st + 1 == kDmaStages) ? 0 : st + 1;
+        st = (st + 1 == STAGES) ? 0 : st + 1;
         if (++kt == nk) {
             epi.finish(ea, acc, ctx);
             kt = 0;
@@ -178,11 +180,12 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
 }
 
 // K is in 4-byte words per row (fp16 operands: elements / 2).  sweep <= 0: a workgroup sweeps every R tile.
-template <class Epi, int BM, int BN, bool HALF = false>
+template <class Epi, int BM, int BN, bool HALF = false, int STAGES = kDmaStages>
 inline int launch_gemm_dma(const float* Rp, int M, const float* Cp, int N, int K, const typename Epi::Args& ea,
                            hipStream_t stream, int sweep = 0) {
-    auto kern = gemm_nt_f32_dma_kernel<Epi, BM, BN, HALF>;
-    constexpr size_t lds = (static_cast<size_t>(kDmaStages) * (BM + BN) * kDmaBK + Epi::kLdsFloats) * sizeof(float);
+    auto kern = gemm_nt_f32_dma_kernel<Epi, BM, BN, HALF, STAGES>;
+    constexpr size_t lds = (static_cast<size_t>(STAGES) * (BM + BN) * kDmaBK + Epi::kLdsFloats) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool configured = false;
     if (!configured) {
         QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

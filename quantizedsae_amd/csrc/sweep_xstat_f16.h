@@ -1,0 +1,325 @@
+// sweep_xstat_f16.h -- the fp16 candidate sweep with the activation panel stationary in registers.
+//
+// Role: step 4 of the prefilter pipeline (encode_topk.hip).  For every activation row b and every swept
+// hidden unit h it forms the approximate latent  v = fma(sum_k xq[b,k] wq[h,k], inv[b], bias[h])  with
+// v_mfma_f32_32x32x16_f16 and appends (v, h) to the row's candidate list when !(v < tau[b] - margin[b]).
+// It returns no values of its own: the refine step recomputes every survivor with the exact fp32 chain.
+//
+// Data movement (the point of this kernel; the generic LDS-DMA GEMM stages BOTH operands for every tile
+// and is bound by ~20 GB/s/CU of DMA, 3.0 ms on the headline shape):
+//   * a workgroup owns 256 activation rows for the whole launch: wave w keeps the B-operand fragments of
+//     rows 32w..32w+31 for all of K in registers (D = 512: 32 k-blocks x 4 VGPRs = 128 VGPRs), loaded once;
+//   * only the fp16 weights stream: HT = 64 hidden rows (D*2 bytes each) per stage, 2 stages in LDS,
+//     written by global_load_lds_dwordx4 one stage ahead; every workgroup streams the same rows in the
+//     same order, so after the first toucher in an XCD the stream is L2 hits;
+//   * staged bytes per MFMA FLOP are 1/256 B (256 x 256 tile: 1/128, 256 x 128: 1/85).
+// LDS image of a stage: row r = CPR 16-byte chunks; chunk j sits at position j ^ (r & 15), applied on the
+// DMA source address and on the fragment read: the four 16-lane groups of a ds_read_b128 (MI355X guide,
+// LDS table) each see 16 rows that are distinct mod 16, i.e. 16 distinct bank groups.
+// Synchronisation: one s_waitcnt vmcnt(0) + s_barrier per stage.  Nothing but the DMA and the (rare)
+// candidate flushes uses the vector memory counter inside the loop: the stage's bias is DMA'd into LDS
+// with the weights, hits collect in per-lane LDS record slots and are flushed (list lengths in registers)
+// at the top of the next stage, *before* that stage's DMA.
+#pragma once
+
+#include "gemm_mfma_f32_dma.h"
+
+namespace qsae {
+
+constexpr int kXsWaves = 8;
+constexpr int kXsRows = 32 * kXsWaves;     // activation rows per workgroup
+constexpr int kXsHT = 64;                  // hidden rows per stage (two MFMA row tiles)
+constexpr int kXsStages = 2;
+constexpr int kXsSlots = 6;                // candidate records per lane between flushes (+1 overflow slot)
+
+struct XsArgs {
+    const _Float16* __restrict__ xq;      // [B][D] scaled fp16 activations
+    const _Float16* __restrict__ wq;      // [Hs][D] fp16 weights of the swept hidden units
+    const float* __restrict__ bias;       // [Hs] or nullptr
+    const float* __restrict__ tau;        // [B]
+    const float* __restrict__ margin;     // [B]
+    const float* __restrict__ inv;        // [B]
+    uint2* __restrict__ cand;             // [B][cap]
+    int* __restrict__ cnt;                // [B] in: seeds already present, out: total
+    int B, Hs, cap, hidden_offset;
+    int rot_mul;             // row rotation of the DMA order per workgroup (see issue())
+    unsigned long long* stamps;   // ABL == 5: per-wave phase cycle totals [wg][wave][8]
+};
+
+template <int KB, int ABL = 0>   // k-blocks of 16 halves: D = 16 * KB; ABL: timing ablations (results wrong)
+__global__ void __launch_bounds__(64 * kXsWaves)
+sweep_xstat_f16_kernel(XsArgs a) {
+    constexpr int D = 16 * KB;
+    constexpr int CPR = 2 * KB;                              // 16-byte chunks per row
+    constexpr int SW = (CPR < 16 ? CPR : 16) - 1;
+    constexpr int STAGE_BYTES = kXsHT * D * 2;
+    constexpr int IPW = (kXsHT * CPR / 64) / kXsWaves;       // DMA instructions per wave per stage
+    constexpr int MT = kXsHT / 32;
+    constexpr int BIAS_BYTES = kXsHT * 4;                    // one stage's bias; three copies in rotation
+    constexpr int BIAS_BASE = kXsStages * STAGE_BYTES;
+    constexpr int RING_BASE = BIAS_BASE + 3 * BIAS_BYTES;
+    constexpr int RING_WAVE = (kXsSlots + 1) * 512;          // [slot][lane] records of 8 bytes
+    constexpr int LDS_END = RING_BASE + kXsWaves * RING_WAVE;
+    static_assert(IPW >= 1 && (kXsHT * CPR) % (64 * kXsWaves) == 0, "stage must split evenly over the waves");
+    static_assert(LDS_END <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char xs_smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform for the compiler, too
+    const int lane_col = lane & 31, lane_half = lane >> 5;
+    const int row = blockIdx.x * kXsRows + wave * 32 + lane_col;
+    const bool row_ok = row < a.B;
+    const int crow = row_ok ? row : a.B - 1;
+
+    const float thr = a.tau[crow] - a.margin[crow];
+    const float inv = a.inv[crow];
+
+    // ---- stationary operand: this lane's 8 halves of every k-block of its activation row -----------
+    f16x8 xf[KB];
+    {
+        const _Float16* xr = a.xq + static_cast<int64_t>(crow) * D + 8 * lane_half;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const f16x8*>(xr + 16 * kb);
+    }
+
+    // ---- DMA addressing: instruction i of this wave covers chunks (wave*IPW + i)*64 .. +63 ---------
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // Workgroups of one XCD stream the same rows in lockstep; started on the same row they would all queue
+    // on the same L2 channel at the same moment.  Each workgroup therefore walks the 1-KiB pieces of a
+    // stage in its own rotation (pieces = 64-chunk groups; the LDS image is unchanged).
+    constexpr int PIECES = kXsHT * CPR / 64;
+    const int rot = ((blockIdx.x >> 3) * a.rot_mul) % PIECES;
+    unsigned voff[IPW];                                      // per-lane byte offsets inside a stage (constant)
+    int piece[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        piece[i] = (wave * IPW + i + rot) % PIECES;
+        const int c = piece[i] * 64 + lane;
+        const int r = c / CPR, pos = c % CPR;
+        voff[i] = static_cast<unsigned>((r * CPR + (pos ^ (r & SW))) * 16);
+    }
+    char* bias_lds = xs_smem + BIAS_BASE;
+    char* my_ring = xs_smem + RING_BASE + wave * RING_WAVE + lane * 8;     // this lane's slot 0
+    if (!a.bias && tid < 3 * kXsHT) reinterpret_cast<float*>(bias_lds)[tid] = 0.f;   // no bias: the copies stay zero
+    const int nstages = a.Hs / kXsHT;
+    int ld = 0;                                              // next stage to issue
+    auto issue = [&]() {
+        char* dst = xs_smem + (ld % kXsStages) * STAGE_BYTES;
+        const char* sb = reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(ld) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(sb + voff[i]), (lptr_t)(dst + piece[i] * 1024), 16, 0, 0);
+        // the stage's bias (kXsHT floats), by wave 0: lanes 0..kXsHT/4-1, 16 bytes each.  Three copies in
+        // rotation: while stage s+1 lands, waves 0..3 still read copy s and waves 4..7 copy s-1.
+        if (a.bias && wave == 0 && lane < kXsHT / 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + static_cast<int64_t>(ld) * kXsHT + 4 * lane),
+                                             (lptr_t)(bias_lds + (ld % 3) * BIAS_BYTES), 16, 0, 0);
+        ++ld;
+    };
+    if (nstages > 0) issue();
+    // Make the compiler retire its own loads (x fragments, threshold, scale) HERE: it cannot see the asm
+    // waits below, and a load still pending in its model at the loop header costs a vmcnt(0) per stage.
+    float thr_r = thr, inv_r = inv;
+    asm volatile("" : "+v"(thr_r), "+v"(inv_r));
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(xf[kb]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- fragment read addressing: chunk (2kb + half) of row lane_col, kb = 8g + j -------------------
+    int off[8];
+    {
+        const int q = (lane_col & SW) ^ lane_half;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) off[j] = lane_col * (CPR * 16) + 16 * (((2 * j) & SW) ^ q) + 16 * ((2 * j) & ~SW);
+    }
+
+    // ---- filter + candidate records ------------------------------------------------------------------
+    // Measured with s_memtime stamps (tools/prof_xstat_phases.py): a filter made of per-value wave
+    // ballots and scalar branches takes ~5000 cycles per stage -- the VALU -> SALU -> branch round trip of
+    // every value is exposed -- more than the stage's MFMAs (2900).  This one is straight-line: per value
+    // a v_fma, the record's tag and slot address, then v_cmpx (EXEC = the lanes at or above their
+    // threshold), a ds_write_b64 of {v, h | row << 27} into the lane's own record slots, EXEC restored and
+    // an add-with-carry on the lane's record count.  No branch, no LDS traffic without a hit, and no
+    // vmcnt(0) in front of the LDS write (the compiler would put one there: it cannot know that the slots
+    // never alias the DMA'd stages).  [slot][lane] image, slot = min(count, kXsSlots): the last slot only
+    // absorbs overflow.  The pilot threshold lets ~300 values per row through, ~0.3 per lane and stage.
+    // The records move to the global lists at the top of the next stage, before that stage's DMA is
+    // issued (the vmcnt(0) at the end of a stage then never waits for the acknowledgement of a store).
+    // A row belongs to lanes l and l+32 of one wave: its list length lives in a register of both, the
+    // partner's record count comes over a ds_bpermute, the lower lane appends first.  A lane that
+    // overflowed its slots pushes the row's length past cap: the row takes the exact fallback like any
+    // other overflowing row.
+    f32x16 acc[MT];
+    int nrec = 0;                                            // records in this lane's slots
+    int count = row_ok ? a.cnt[crow] : 0;                    // the row's list length (equal in both lanes)
+    uint2* list = a.cand + static_cast<int64_t>(crow) * a.cap;
+    typedef __attribute__((address_space(3))) char* lds_char_t;
+    const unsigned ring_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char_t)my_ring));   // LDS byte address
+    auto flush = [&]() {
+        if (__builtin_amdgcn_ballot_w64(nrec > 0) != 0ull) {
+            asm volatile("" ::: "memory");
+            const int n_other = __shfl_xor(nrec, 32, 64);
+            int pos = count + (lane_half ? (n_other < kXsSlots ? n_other : kXsSlots) : 0);
+            const int mine = nrec < kXsSlots ? nrec : kXsSlots;
+            uint2 rec[kXsSlots];
+#pragma unroll
+            for (int j = 0; j < kXsSlots; ++j) rec[j] = *reinterpret_cast<const uint2*>(my_ring + j * 512);
+#pragma unroll
+            for (int j = 0; j < kXsSlots; ++j) {
+                if (j < mine && row_ok && ABL != 3 && pos + j < a.cap)
+                    list[pos + j] = make_uint2(rec[j].x, rec[j].y & 0x07FFFFFFu);
+            }
+            count += mine + (n_other < kXsSlots ? n_other : kXsSlots);
+            if (nrec > kXsSlots || n_other > kXsSlots) count = a.cap + 1;     // lost records: exact fallback
+            asm volatile("" ::: "memory");
+            nrec = 0;
+        }
+    };
+    auto filter = [&](int st) {
+        const char* bb = bias_lds + (st % 3) * BIAS_BYTES + 16 * lane_half;
+        // hidden index of accumulator register 0 of row tile 0 for this lane, tagged with its row
+        const unsigned tag = static_cast<unsigned>(st * kXsHT + a.hidden_offset + 4 * lane_half) |
+                             (static_cast<unsigned>(lane_col) << 27);
+        // register quad g of row tile mt: hidden rows 32mt + 8g + (0..3) [+4 for the upper half-wave]
+        f32x4 bvv[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bvv[mt][g] = *reinterpret_cast<const f32x4*>(bb + (mt * 32 + 8 * g) * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = bvv[mt][g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = fmaf(acc[mt][4 * g + i], inv_r, bv[i]);
+                    const unsigned t = tag + static_cast<unsigned>(mt * 32 + 8 * g + i);
+                    const unsigned long long data = (static_cast<unsigned long long>(t) << 32) | __float_as_uint(v);
+                    const unsigned slot = static_cast<unsigned>(nrec < kXsSlots ? nrec : kXsSlots);
+                    const unsigned addr = ring_addr + slot * 512u;
+                    const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_r;
+                    // EXEC <- !(v < thr) (at or above the threshold, or NaN); write; EXEC <- all; nrec += hit
+                    asm volatile("v_cmpx_nlt_f32_e32 vcc, %[v], %[thr]\n\t"
+                                 "ds_write_b64 %[addr], %[data]\n\t"
+                                 "s_mov_b64 exec, -1\n\t"
+                                 "v_addc_co_u32_e32 %[n], vcc, 0, %[n], vcc"
+                                 : [n] "+v"(nrec)
+                                 : [v] "v"(v), [thr] "v"(cmp), [addr] "v"(addr), [data] "v"(data)
+                                 : "vcc", "memory");
+                }
+            }
+    };
+
+    // The two waves of a SIMD (w and w+4) run half a stage out of phase: waves 0..3 filter a stage right
+    // after its MFMAs, waves 4..7 at the top of the next stage, so one of the two always has MFMAs to issue.
+    const bool late = wave >= kXsWaves / 2;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int which) {
+        if (ABL >= 5) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            tacc[which] += t - tprev;
+            tprev = t;
+        }
+    };
+    if (ABL >= 5) tprev = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int s = 0; s < nstages; ++s) {
+        if (late && s > 0 && ABL != 2 && ABL != 8) filter(s - 1);
+        flush();                                             // older than the DMA issued next
+        stamp(0);
+        if (ld < nstages) issue();                           // stage s+1 -> the buffer read during stage s-1
+        stamp(1);
+        const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        // Fragment reads run one group (GK k-blocks x MT row tiles) ahead of the MFMAs that consume them;
+        // the sched_barriers pin that order.  kb = 8g + j: the chunk positions repeat every 8 k-blocks,
+        // 256 bytes apart; row tile mt is 32 rows = 32 * CPR * 16 bytes further.
+        constexpr int GK = 2, NG = KB / GK;
+        auto rd = [&](int mt, int kb) {
+            return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
+        };
+        f16x8 wf[2][GK][MT];
+#pragma unroll
+        for (int j = 0; j < GK; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) wf[0][j][mt] = rd(mt, j);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int j = 0; j < GK; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) wf[(g + 1) & 1][j][mt] = rd(mt, (g + 1) * GK + j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < GK; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[g & 1][j][mt], xf[g * GK + j], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ABL >= 5) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }   // MFMA results have landed
+        stamp(2);
+        if (!late && ABL != 2 && ABL != 8) filter(s);
+        stamp(3);
+        // retire stage s+1 (for every wave) before anyone reads it; also frees this stage's buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
+        __builtin_amdgcn_s_barrier();
+        stamp(5);
+    }
+    if (ABL >= 5 && a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * kXsWaves + wave) * 8 + i] = tacc[i];
+    }
+    if (late && nstages > 0 && ABL != 2) filter(nstages - 1);
+    flush();
+    if (row_ok && lane_half == 0) a.cnt[row] = count;
+}
+
+inline bool xstat_supported(int D, int Hs, int hidden_offset) {
+    return (D == 512 || D == 256 || D == 128) && Hs > 0 && Hs % kXsHT == 0 && hidden_offset % 4 == 0 &&
+           static_cast<int64_t>(hidden_offset) + Hs <= (1 << 27);      // 27-bit hidden index in a ring record
+}
+
+template <int KB, int ABL = 0>
+inline int launch_xstat_one(const XsArgs& a, hipStream_t stream) {
+    constexpr size_t lds = static_cast<size_t>(kXsStages) * kXsHT * 16 * KB * 2 +
+                           3 * kXsHT * 4 + static_cast<size_t>(kXsWaves) * (kXsSlots + 1) * 512;
+    auto kern = sweep_xstat_f16_kernel<KB, ABL>;
+    static bool configured = false;
+    if (!configured) {
+        QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.B + kXsRows - 1) / kXsRows), dim3(64 * kXsWaves), lds, stream, a);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+inline int launch_xstat(int D, const XsArgs& a, hipStream_t stream, int ablate = 0) {
+    if (D == 512 && ablate == 1) return launch_xstat_one<32, 1>(a, stream);
+    if (D == 512 && ablate == 2) return launch_xstat_one<32, 2>(a, stream);
+    if (D == 512 && ablate == 3) return launch_xstat_one<32, 3>(a, stream);
+    if (D == 512 && ablate == 4) return launch_xstat_one<32, 4>(a, stream);
+    if (D == 512 && ablate == 5) return launch_xstat_one<32, 5>(a, stream);
+    if (D == 512 && ablate == 6) return launch_xstat_one<32, 6>(a, stream);
+    if (D == 512 && ablate == 7) return launch_xstat_one<32, 7>(a, stream);
+    if (D == 512 && ablate == 8) return launch_xstat_one<32, 8>(a, stream);
+    switch (D) {
+        case 512: return launch_xstat_one<32>(a, stream);
+        case 256: return launch_xstat_one<16>(a, stream);
+        case 128: return launch_xstat_one<8>(a, stream);
+        default: return fail(QSAE_ERR_UNSUPPORTED, "%s: D must be 128, 256 or 512", __func__);
+    }
+}
+
+}  // namespace qsae
