@@ -30,6 +30,7 @@ int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* 
                        float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s,
                        const float* margin = nullptr);
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
+int densify_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
 constexpr int kCandCap = 1024;     // candidate slots per row
@@ -40,6 +41,9 @@ static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
+static unsigned long long* g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
+static int g_ref_ablate = 0;        // timing experiments on the refine kernel (results wrong when non-zero)
+static int g_last_flagged = 0;      // rows the last fused / prefilter call sent through the exact fallback
 static int g_xstat_ablate = 0;     // timing experiments only (results are wrong when non-zero)
 static int g_pref_tile = 2;        // fp16 sweep: 2 = activation-stationary kernel (where supported), 0 = 256 x 256 tile
                                    // (2 stages), 1 = 256 x 128 tile (3 stages)
@@ -337,6 +341,7 @@ static int run_flagged_rows(const float* x, const float* W, const float* bias, i
     int nflag = 0;
     QSAE_HIP(hipMemcpyAsync(&nflag, flags, sizeof(int), hipMemcpyDeviceToHost, s));
     QSAE_HIP(hipStreamSynchronize(s));
+    g_last_flagged = nflag;
     if (nflag <= 0) return QSAE_OK;
     float* fx = reinterpret_cast<float*>(ws + L.fx);
     float* flat = reinterpret_cast<float*>(ws + L.flat);
@@ -593,30 +598,46 @@ struct EpiApproxDense {
 };
 
 // ---- refine: approximate k-th -> survivors -> exact fp32 chain -> exact top-k; one wave per row --------
+// The kernel is latency- and issue-bound, not bandwidth-bound (s_memtime stamps, tools/prof_refine_phases.py:
+// 72 us per row and wave, half of it outside the W gather), so it is written for short code and few round
+// trips: row scalars (count, tau, margin) and the activation row come through scalar loads (the row is the
+// wave-uniform operand of every FMA: v_fmac with an SGPR source, no LDS copy); the candidate list is loaded
+// with all slots in flight; the approximate k-th largest is a 32-bit bisection on the monotone value keys
+// (only its VALUE is needed, ties are irrelevant); kRefSets W blocks stay in flight during the chains (the
+// LDS hand-offs inside a wave need no fence -- one wave's LDS operations execute in order -- and a fence
+// would drain the load queue).
 constexpr int kRefWaves = 4;
-constexpr int kRefMaxD = 2048;     // activation row cached in LDS
-constexpr int kRefMaxSurv = 512;   // survivors per row (more -> flagged, exact fallback)
+constexpr int kRefMaxD = 2048;
+constexpr int kRefSets = 3;        // W blocks in flight per wave
+constexpr int kRefMaxSurv = 256;   // survivors per row (more -> flagged, exact fallback)
 constexpr int kRefTileStride = 36; // floats per transposed-tile row (32 + 4 pad: conflict-free b128 access)
-// dynamic LDS per wave: x row [D] | transposed W tile [64][36] | exact keys [512] u64 | hidden index / value [512]
-static inline size_t ref_lds_per_wave(int D) {
-    return static_cast<size_t>(D) * 4 + 64 * kRefTileStride * 4 + kRefMaxSurv * 8 + kRefMaxSurv * 4;
+// dynamic LDS per wave: exact keys [512] u64 | transposed W tile [64][36] | hidden index / value [512]
+__host__ __device__ static inline size_t ref_lds_per_wave(int) {
+    return static_cast<size_t>(kRefMaxSurv) * 8 + 64 * kRefTileStride * 4 + kRefMaxSurv * 4;
 }
 
 __global__ void __launch_bounds__(64 * kRefWaves)
 refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
                    const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
-                   float* __restrict__ val_out, int* __restrict__ flags) {
+                   float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * kRefWaves + wave;
+    // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
+    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int which) {
+        if (stamps) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[which], t - tprev);
+            tprev = t;
+        }
+    };
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kRefWaves + wave;                       // wave-uniform
     if (b >= B) return;
-    // per-wave carve (every wave works alone: ordering inside a wave comes from the in-order LDS queue)
-    unsigned char* mybase = ref_smem + static_cast<size_t>(wave) * (static_cast<size_t>(D) * 4 + 64 * kRefTileStride * 4 +
-                                                                     kRefMaxSurv * 8 + kRefMaxSurv * 4);
+    unsigned char* mybase = ref_smem + static_cast<size_t>(wave) * ref_lds_per_wave(D);
     unsigned long long* ekey = reinterpret_cast<unsigned long long*>(mybase);
-    float* xs = reinterpret_cast<float*>(mybase + kRefMaxSurv * 8);
-    float* wt = xs + D;
+    float* wt = reinterpret_cast<float*>(mybase + kRefMaxSurv * 8);
     int* hidx = reinterpret_cast<int*>(wt + 64 * kRefTileStride);
     auto flag_row = [&]() {
         if (lane == 0) {
@@ -624,70 +645,99 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
             flags[1 + slot] = b;
         }
     };
-    const int n = cnt[b];
+    auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };       // in-order LDS queue: compiler barrier only
+    // row scalars through the constant address space (written by earlier launches only): s_load, no VGPRs
+    typedef const __attribute__((address_space(4))) int* cint_t;
+    typedef const __attribute__((address_space(4))) float* cflt_t;
+    const int n = ((cint_t)cnt)[b];
+    const float tau_b = ((cflt_t)tau)[b];
+    const float margin_b = ((cflt_t)margin)[b];
     if (n < k || n > cap) { flag_row(); return; }
-    // ---- approximate k-th largest (same MSB-first bisection as select_topk_kernel) -----------------
-    unsigned long long key[kSelSlots];
-    float aval[kSelSlots];
+    // ---- candidate list -> LDS (the W tile's space: value keys [1024] | hidden indices [1024]) ----------
+    // Keys live in LDS, not in 16 register slots per lane: short loops instead of 4000 lines of unrolled
+    // select code, and the registers go to the W staging sets.
     const uint2* list = cand + static_cast<int64_t>(b) * cap;
-    const int nslots = (n + 63) / 64;
-#pragma unroll
-    for (int s = 0; s < kSelSlots; ++s) {
+    const int nslots = (n + 63) / 64;                                  // wave-uniform
+    uint32_t* lkey = reinterpret_cast<uint32_t*>(wt);                  // 0 = no candidate (mono keys are >= 0x007FFFFF)
+    uint32_t* lidx = lkey + kCandCap;
+    static_assert(2 * kCandCap * 4 <= 64 * kRefTileStride * 4, "candidate keys must fit the W tile");
+    bool any_nan = false;
+    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
+    for (int s = 0; s < nslots; ++s) {
         const int i = s * 64 + lane;
-        key[s] = 0ull;
-        aval[s] = -__builtin_huge_valf();
-        if (s < nslots && i < n) {
+        uint32_t kk = 0u;
+        if (i < n) {
             const uint2 c = list[i];
-            aval[s] = __uint_as_float(c.x);
-            key[s] = (static_cast<unsigned long long>(mono_key(aval[s])) << 16) |
-                     static_cast<unsigned long long>((H - 1) - static_cast<int>(c.y));
+            const float v = __uint_as_float(c.x);
+            kk = mono_key(v);
+            any_nan |= (v != v);
+            all_or |= kk;
+            all_and &= kk;
+            lidx[i] = c.y;
         }
+        lkey[i] = kk;
     }
-    unsigned long long T = 0ull;
+    if (__any(any_nan)) { flag_row(); return; }                        // NaN latents: let the exact path rank them
+    lds_handoff();
+    stamp(0);
+    // ---- approximate k-th largest VALUE: MSB-first bisection below the highest differing bit -------------
+    for (int off = 32; off > 0; off >>= 1) {
+        all_or |= __shfl_xor(all_or, off, 64);
+        all_and &= __shfl_xor(all_and, off, 64);
+    }
+    const uint32_t diff = all_or ^ all_and;
+    uint32_t T = all_and & ~(diff ? (0xFFFFFFFFu >> __builtin_clz(diff)) : 0u);   // common prefix
     int at_or_above = n;
-    for (int bit = 47; bit >= 0; --bit) {
+    for (int bit = diff ? 31 - __builtin_clz(diff) : -1; bit >= 0; --bit) {
         if (at_or_above == k) break;
-        const unsigned long long trial = T | (1ull << bit);
+        const uint32_t trial = T | (1u << bit);
         int c = 0;
-        for (int s = 0; s < nslots; ++s) c += __popcll(__ballot(key[s] >= trial));
+        for (int s = 0; s < nslots; ++s) c += __popcll(__ballot(lkey[s * 64 + lane] >= trial));
         if (c >= k) { T = trial; at_or_above = c; }
     }
-    // t~ = smallest approximate value inside the approximate top-k
-    float tk = __builtin_huge_valf();
-    bool any_nan = false;
+    stamp(1);
+    // t~ = smallest approximate key inside the approximate top-k (the k-th largest when at_or_above == k,
+    // otherwise the tie key T itself); keys are monotone in the value, so min over keys = min over values
+    uint32_t tkey = 0xFFFFFFFFu;
     for (int s = 0; s < nslots; ++s) {
-        if (key[s] >= T && key[s] != 0ull) {
-            if (aval[s] != aval[s]) any_nan = true; else tk = fminf(tk, aval[s]);
-        }
+        const uint32_t kk = lkey[s * 64 + lane];
+        if (kk >= T && kk < tkey) tkey = kk;
     }
-    for (int off = 32; off > 0; off >>= 1) tk = fminf(tk, __shfl_xor(tk, off, 64));
-    if (__any(any_nan)) { flag_row(); return; }            // NaN latents: let the exact path rank them
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(tkey, off, 64);
+        tkey = o < tkey ? o : tkey;
+    }
+    // key -> value (inverse of mono_key on non-NaN keys)
+    const float tk = __uint_as_float((tkey & 0x80000000u) ? (tkey & 0x7FFFFFFFu) : ~tkey);
     // the list holds everything >= tau - margin; t~ must not lie below tau or survivors could be missing
-    if (!(tk >= tau[b])) { flag_row(); return; }
-    const float cut = tk - margin[b];
+    if (!(tk >= tau_b)) { flag_row(); return; }
+    const uint32_t cutkey = mono_key(tk - margin_b);                   // keep <=> !(value < cut) <=> key >= cutkey
     // ---- survivors -> LDS ----------------------------------------------------------------------------
     int m = 0;
     for (int s = 0; s < nslots; ++s) {
-        const bool keep = key[s] != 0ull && !(aval[s] < cut);
+        const int i = s * 64 + lane;
+        const uint32_t kk = lkey[i];
+        const bool keep = kk != 0u && kk >= cutkey;
         const unsigned long long msk = __ballot(keep);
         if (keep) {
             const int pos = m + __popcll(msk & ((1ull << lane) - 1ull));
-            if (pos < kRefMaxSurv) hidx[pos] = (H - 1) - static_cast<int>(key[s] & 0xFFFFull);
+            if (pos < kRefMaxSurv) hidx[pos] = static_cast<int>(lidx[i]);
         }
         m += __popcll(msk);
     }
     if (m > kRefMaxSurv) { flag_row(); return; }
-    for (int d = lane; d < D; d += 64) xs[d] = x[static_cast<int64_t>(b) * D + d];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lds_handoff();
+    stamp(2);
+    stamp(3);
     // ---- exact fp32 chain per survivor (ascending k, seeded with the bias: the oracle's arithmetic) ---
     // A chain is sequential in k, so one lane owns one survivor; but 64 lanes walking 64 different W rows
     // 16 bytes at a time touch 64 cache lines per load.  Instead the wave fetches [64 survivors x 32 k]
     // blocks line-wise (8 lanes per 128-byte row segment), transposes them through LDS, and every lane
     // then reads its own row's 32 values from there: each W line is fetched once.
-    const int nblk = D / 32;                                   // D % 64 == 0: even
-    for (int j0 = 0; j0 < m; j0 += 64) {
+    typedef const __attribute__((address_space(4))) f32x4* cvec_t;
+    cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);          // wave-uniform: scalar loads
+    const int nblk = D / 32;
+    for (int j0 = 0; j0 < (ablate == 2 ? 0 : m); j0 += 64) {
         const int j = j0 + lane;
         const int h = (j < m) ? hidx[j] : hidx[j0];
         float acc = bias ? bias[h] : 0.0f;
@@ -697,56 +747,59 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         for (int i = 0; i < 8; ++i) {
             int jj = j0 + 8 * i + (lane >> 3);
             jj = jj < m ? jj : j0;
-            rp[i] = W + static_cast<int64_t>(hidx[jj]) * D + 4 * (lane & 7);
+            rp[i] = W + static_cast<int64_t>(ablate == 1 ? (lane >> 3) : hidx[jj]) * D + 4 * (lane & 7);
         }
-        // two staging sets, two blocks in flight
-        f32x4 s0[8], s1[8];
+        f32x4 st[kRefSets][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s0[i] = *reinterpret_cast<const f32x4*>(rp[i]);
+        for (int q = 0; q < kRefSets; ++q)
+            if (q < nblk) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s1[i] = *reinterpret_cast<const f32x4*>(rp[i] + 32);
-        auto consume = [&](const f32x4 (&st)[8], int t) {
+                for (int i = 0; i < 8; ++i) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * q);
+            }
+        auto consume = [&](const f32x4 (&sv)[8], int t) {
+            f32x4 xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = xrow[8 * t + q];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = st[i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+            lds_handoff();
             const float* mine = wt + lane * kRefTileStride;
+            f32x4 w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
+            lds_handoff();
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(mine + 4 * q);
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 32 * t + 4 * q);
-                acc = fmaf(xv[0], w[0], acc);
-                acc = fmaf(xv[1], w[1], acc);
-                acc = fmaf(xv[2], w[2], acc);
-                acc = fmaf(xv[3], w[3], acc);
+                acc = fmaf(xv[q][0], w[q][0], acc);
+                acc = fmaf(xv[q][1], w[q][1], acc);
+                acc = fmaf(xv[q][2], w[q][2], acc);
+                acc = fmaf(xv[q][3], w[q][3], acc);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
         };
-        for (int t = 0; t < nblk; t += 2) {
-            consume(s0, t);
-            if (t + 2 < nblk) {
+        for (int t = 0; t < nblk; t += kRefSets) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s0[i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + 2));
-            }
-            consume(s1, t + 1);
-            if (t + 3 < nblk) {
+            for (int q = 0; q < kRefSets; ++q) {
+                if (t + q < nblk) {
+                    consume(st[q], t + q);
+                    if (t + q + kRefSets < nblk) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s1[i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + 3));
+                        for (int i = 0; i < 8; ++i)
+                            st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + q + kRefSets));
+                    }
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        lds_handoff();
         if (j < m) {
             ekey[j] = full_key(acc, static_cast<uint32_t>(h));
             // keep the exact bits next to the key (NaN payloads / -0 are not recoverable from the key)
             reinterpret_cast<float*>(hidx)[j] = acc;     // hidx[j] is consumed; reuse the slot for the value
         }
+        lds_handoff();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lds_handoff();
+    stamp(4);
     // ---- exact rank among the survivors ----------------------------------------------------------------
     for (int j = lane; j < m; j += 64) {
         const unsigned long long mine = ekey[j];
@@ -757,21 +810,11 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
             val_out[static_cast<int64_t>(b) * k + rank] = reinterpret_cast<const float*>(hidx)[j];
         }
     }
+    stamp(5);
 }
 
 static bool prefilter_shape_ok(int B, int D, int H, int k) {
     return use_fused(B, D, H, k) && D % 64 == 0 && D <= kRefMaxD && (H - pilot_width(H)) > 0;
-}
-
-// dense latent = zeros (the k survivors are scattered in afterwards): one row per workgroup pass, 16-byte
-// stores, consecutive threads -> consecutive chunks
-__global__ void __launch_bounds__(256)
-zero_rows_kernel(float* __restrict__ dense, int64_t ld, int B, int H4) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int row = blockIdx.x; row < B; row += gridDim.x) {
-        f32x4* out = reinterpret_cast<f32x4*>(dense + static_cast<int64_t>(row) * ld);
-        for (int c = threadIdx.x; c < H4; c += 256) out[c] = z;
-    }
 }
 
 static int run_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
@@ -790,14 +833,11 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     float* inv = reinterpret_cast<float*>(ws + PL.inv);
     float* margin = reinterpret_cast<float*>(ws + PL.margin);
     QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
-    // The fp16 sweep is bound by memory traffic, so the dense latent's zero-fill is cheaper as a
-    // bandwidth-saturating pass of its own than folded into the sweep epilogue (measured 1.25 vs 1.65 ms).
+    // With the activation-stationary sweep nothing upstream touches the dense latent: it is written once at
+    // the end (zeros + the k survivors of every row in one pass, densify_rows).  The LDS-tiled sweep kernels
+    // zero-fill their own blocks in the epilogue instead and the survivors are scattered in afterwards.
     const bool xstat = g_pref_tile == 2 && xstat_supported(D, H - P, P) && H % 4 == 0;
     float* fused_fill = xstat ? nullptr : dense;
-    if (dense && xstat) {
-        hipLaunchKernelGGL(zero_rows_kernel, dim3(B < 16384 ? B : 16384), dim3(256), 0, s, dense, dense_ld, B, H / 4);
-        QSAE_LAUNCH_CHECK();
-    }
     // 1. fp16 copy of the batch + per-row scale and error margin
     hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
     QSAE_LAUNCH_CHECK();
@@ -856,13 +896,14 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
             configured = true;
         }
         hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
-                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags);
+                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps);
     }
     QSAE_LAUNCH_CHECK();
     // 6. flagged rows through the exact unfused kernels
     rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false);
     if (rc != QSAE_OK) return rc;
-    if (dense) return scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
+    if (dense) return xstat ? densify_rows(idx, val, B, k, H, dense, dense_ld, s)
+                            : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
 }
 
@@ -900,6 +941,18 @@ extern "C" int qsae_debug_set_xstat_stamps(void* buf) {
     g_xstat_stamps = static_cast<unsigned long long*>(buf);
     return QSAE_OK;
 }
+
+extern "C" int qsae_debug_set_refine_stamps(void* buf) {
+    g_ref_stamps = static_cast<unsigned long long*>(buf);
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_set_refine_ablate(int v) {
+    g_ref_ablate = v;
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_last_flagged() { return g_last_flagged; }
 
 extern "C" int qsae_debug_set_xstat_rot(int rot) {
     g_xstat_rot = rot;

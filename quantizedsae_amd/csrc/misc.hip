@@ -78,6 +78,23 @@ pack_bits_gt_kernel(const float* __restrict__ dense, int64_t ld, int B, int H, f
 }
 
 // scatter without the preceding zero fill (the fused encoder zero-fills the dense latent itself)
+int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
+
+// zeros + the k survivors of every row.  Measured on the [65536, 32768] latent: the runtime's linear fill
+// (6.9 TB/s) + the scatter kernel take 1.63 ms; a fused kernel that writes whole rows per workgroup (zeros,
+// vmcnt(0) + barrier, survivors) took 2.1 ms -- 2048 concurrent rows 128 KiB apart lose the DRAM page
+// locality of a linear sweep.
+int densify_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s) {
+    if (B == 0) return QSAE_OK;
+    if (ld == H) {
+        QSAE_HIP(hipMemsetAsync(dense, 0, static_cast<size_t>(B) * H * sizeof(float), s));
+    } else {
+        QSAE_HIP(hipMemset2DAsync(dense, static_cast<size_t>(ld) * sizeof(float), 0,
+                                  static_cast<size_t>(H) * sizeof(float), B, s));
+    }
+    return scatter_rows(idx, val, B, k, H, dense, ld, s);
+}
+
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s) {
     const long long total = static_cast<long long>(B) * k;
     if (total == 0) return QSAE_OK;
@@ -144,19 +161,10 @@ extern "C" int qsae_densify(const int32_t* idx, const float* val, int B, int k, 
     if (B == 0) return QSAE_OK;
     QSAE_CHECK_ARG(idx && val && dense, "null pointer");
     QSAE_CHECK_ARG(ld >= H, "ld < H");
-    hipStream_t s = as_stream(stream);
-    if (ld == H) {
-        QSAE_HIP(hipMemsetAsync(dense, 0, static_cast<size_t>(B) * H * sizeof(float), s));
-    } else {
-        QSAE_HIP(hipMemset2DAsync(dense, static_cast<size_t>(ld) * sizeof(float), 0,
-                                  static_cast<size_t>(H) * sizeof(float), B, s));
-    }
-    const long long total = static_cast<long long>(B) * k;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, idx,
-                       val, total, k, H, dense, ld);
-    QSAE_LAUNCH_CHECK();
-    return QSAE_OK;
+    return densify_rows(idx, val, B, k, H, dense, ld, as_stream(stream));
 }
+
+
 
 extern "C" int qsae_sq_err_sum(const float* recon, const float* x, size_t n, double* sum, qsae_stream_t stream) {
     if (n == 0) return QSAE_OK;

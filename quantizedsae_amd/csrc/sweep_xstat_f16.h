@@ -177,45 +177,45 @@ sweep_xstat_f16_kernel(XsArgs a) {
             nrec = 0;
         }
     };
-    auto filter = [&](int st) {
-        const char* bb = bias_lds + (st % 3) * BIAS_BYTES + 16 * lane_half;
-        // hidden index of accumulator register 0 of row tile 0 for this lane, tagged with its row
-        const unsigned tag = static_cast<unsigned>(st * kXsHT + a.hidden_offset + 4 * lane_half) |
-                             (static_cast<unsigned>(lane_col) << 27);
-        // register quad g of row tile mt: hidden rows 32mt + 8g + (0..3) [+4 for the upper half-wave]
-        f32x4 bvv[MT][4];
+    // One value of the filter: accumulator register q of row tile mt, stage st (bias quad bq = rows 8g..8g+3
+    // [+4 for the upper half-wave] of that tile, g = q / 4).
+    auto filter_value = [&](int mt, int q, unsigned tag, const f32x4& bq) {
+        const float v = fmaf(acc[mt][q], inv_r, bq[q & 3]);
+        const unsigned t = tag + static_cast<unsigned>(mt * 32 + 8 * (q >> 2) + (q & 3));
+        const unsigned long long data = (static_cast<unsigned long long>(t) << 32) | __float_as_uint(v);
+        const unsigned slot = static_cast<unsigned>(nrec < kXsSlots ? nrec : kXsSlots);
+        const unsigned addr = ring_addr + slot * 512u;
+        const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_r;
+        // EXEC <- !(v < thr) (at or above the threshold, or NaN); write; EXEC <- all; nrec += hit
+        asm volatile("v_cmpx_nlt_f32_e32 vcc, %[v], %[thr]\n\t"
+                     "ds_write_b64 %[addr], %[data]\n\t"
+                     "s_mov_b64 exec, -1\n\t"
+                     "v_addc_co_u32_e32 %[n], vcc, 0, %[n], vcc"
+                     : [n] "+v"(nrec)
+                     : [v] "v"(v), [thr] "v"(cmp), [addr] "v"(addr), [data] "v"(data)
+                     : "vcc", "memory");
+    };
+    // hidden index of accumulator register 0 of row tile 0 for this lane in stage st, tagged with its row
+    auto stage_tag = [&](int st) {
+        return static_cast<unsigned>(st * kXsHT + a.hidden_offset + 4 * lane_half) |
+               (static_cast<unsigned>(lane_col) << 27);
+    };
+    auto load_bias = [&](int st, int mt, f32x4 (&bq)[4]) {
+        const char* bb = bias_lds + (st % 3) * BIAS_BYTES + 16 * lane_half + mt * 128;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bvv[mt][g] = *reinterpret_cast<const f32x4*>(bb + (mt * 32 + 8 * g) * 4);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bv = bvv[mt][g];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = fmaf(acc[mt][4 * g + i], inv_r, bv[i]);
-                    const unsigned t = tag + static_cast<unsigned>(mt * 32 + 8 * g + i);
-                    const unsigned long long data = (static_cast<unsigned long long>(t) << 32) | __float_as_uint(v);
-                    const unsigned slot = static_cast<unsigned>(nrec < kXsSlots ? nrec : kXsSlots);
-                    const unsigned addr = ring_addr + slot * 512u;
-                    const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_r;
-                    // EXEC <- !(v < thr) (at or above the threshold, or NaN); write; EXEC <- all; nrec += hit
-                    asm volatile("v_cmpx_nlt_f32_e32 vcc, %[v], %[thr]\n\t"
-                                 "ds_write_b64 %[addr], %[data]\n\t"
-                                 "s_mov_b64 exec, -1\n\t"
-                                 "v_addc_co_u32_e32 %[n], vcc, 0, %[n], vcc"
-                                 : [n] "+v"(nrec)
-                                 : [v] "v"(v), [thr] "v"(cmp), [addr] "v"(addr), [data] "v"(data)
-                                 : "vcc", "memory");
-                }
-            }
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bb + 32 * g);
     };
 
-    // The two waves of a SIMD (w and w+4) run half a stage out of phase: waves 0..3 filter a stage right
-    // after its MFMAs, waves 4..7 at the top of the next stage, so one of the two always has MFMAs to issue.
-    const bool late = wave >= kXsWaves / 2;
+    // ---- main loop ---------------------------------------------------------------------------------------
+    // A wave hides its own epilogue: the 32 MFMAs of row tile 0 of stage s carry the filter of row tile 1 of
+    // stage s-1 in their shadows (one value = 8 instructions per two MFMAs), the 32 MFMAs of row tile 1 carry
+    // the filter of row tile 0 of stage s.  (With the filter after the MFMAs of a stage, even with the two
+    // waves of a SIMD run out of phase, a stage took 8300 cycles: each wave's MFMA phase (2900) and filter
+    // (2800) are serial, and the other wave's MFMAs slow the filter down to ~10 cycles per instruction.)
+    // The sched_barriers pin the interleave and keep the fragment reads one group ahead of their MFMAs.
+    // kb = 8g + j: the chunk positions repeat every 8 k-blocks, 256 bytes apart; row tile mt is 32 rows =
+    // 32 * CPR * 16 bytes further.
+    static_assert(MT == 2 && KB % 4 == 0, "the interleave below is written for two row tiles");
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int which) {
         if (ABL >= 5) {
@@ -225,49 +225,55 @@ sweep_xstat_f16_kernel(XsArgs a) {
         }
     };
     if (ABL >= 5) tprev = __builtin_amdgcn_s_memtime();
+    constexpr bool FILTER = ABL != 2 && ABL != 8;
+    constexpr int VPG = 32 / KB;                             // filter values per pair of MFMAs (KB = 32: 1)
+    static_assert(VPG >= 1 && VPG * (KB / 2) == 16, "16 values spread over KB/2 MFMA pairs");
+    auto tile_pass = [&](const char* sbase, int mt, bool do_filter, int fmt, int fst) {
+        // MFMAs of row tile mt over all of K; in their shadows the filter of acc[fmt] (stage fst)
+        auto rd = [&](int kb) {
+            return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
+        };
+        f32x4 bq[4];
+        const unsigned tag = stage_tag(fst);
+        if (FILTER && do_filter) load_bias(fst, fmt, bq);
+        f16x8 w0 = rd(0), w1 = rd(1), w2, w3;
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; kb += 4) {
+            w2 = rd(kb + 2); w3 = rd(kb + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[kb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xf[kb + 1], c, 0, 0, 0);
+            if (FILTER && do_filter) {
+#pragma unroll
+                for (int u = 0; u < VPG; ++u) filter_value(fmt, (kb / 2) * VPG + u, tag, bq[((kb / 2) * VPG + u) >> 2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 4 < KB) { w0 = rd(kb + 4); w1 = rd(kb + 5); }
+            __builtin_amdgcn_sched_barrier(0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xf[kb + 2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3, xf[kb + 3], c, 0, 0, 0);
+            if (FILTER && do_filter) {
+#pragma unroll
+                for (int u = 0; u < VPG; ++u)
+                    filter_value(fmt, (kb / 2 + 1) * VPG + u, tag, bq[((kb / 2 + 1) * VPG + u) >> 2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[mt] = c;
+    };
 #pragma unroll 1
     for (int s = 0; s < nstages; ++s) {
-        if (late && s > 0 && ABL != 2 && ABL != 8) filter(s - 1);
         flush();                                             // older than the DMA issued next
         stamp(0);
         if (ld < nstages) issue();                           // stage s+1 -> the buffer read during stage s-1
         stamp(1);
         const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-        // Fragment reads run one group (GK k-blocks x MT row tiles) ahead of the MFMAs that consume them;
-        // the sched_barriers pin that order.  kb = 8g + j: the chunk positions repeat every 8 k-blocks,
-        // 256 bytes apart; row tile mt is 32 rows = 32 * CPR * 16 bytes further.
-        constexpr int GK = 2, NG = KB / GK;
-        auto rd = [&](int mt, int kb) {
-            return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
-        };
-        f16x8 wf[2][GK][MT];
-#pragma unroll
-        for (int j = 0; j < GK; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) wf[0][j][mt] = rd(mt, j);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int j = 0; j < GK; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) wf[(g + 1) & 1][j][mt] = rd(mt, (g + 1) * GK + j);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < GK; ++j)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[g & 1][j][mt], xf[g * GK + j], acc[mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ABL >= 5) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }   // MFMA results have landed
+        tile_pass(sbase, 0, s > 0, 1, s - 1);
         stamp(2);
-        if (!late && ABL != 2 && ABL != 8) filter(s);
+        tile_pass(sbase, 1, true, 0, s);
         stamp(3);
         // retire stage s+1 (for every wave) before anyone reads it; also frees this stage's buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -275,11 +281,18 @@ sweep_xstat_f16_kernel(XsArgs a) {
         __builtin_amdgcn_s_barrier();
         stamp(5);
     }
+    if (ABL >= 5) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }
     if (ABL >= 5 && a.stamps && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * kXsWaves + wave) * 8 + i] = tacc[i];
     }
-    if (late && nstages > 0 && ABL != 2) filter(nstages - 1);
+    if (FILTER && nstages > 0) {
+        f32x4 bq[4];
+        load_bias(nstages - 1, 1, bq);
+        const unsigned tag = stage_tag(nstages - 1);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) filter_value(1, q, tag, bq[q >> 2]);
+    }
     flush();
     if (row_ok && lane_half == 0) a.cnt[row] = count;
 }

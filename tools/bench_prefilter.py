@@ -22,6 +22,7 @@ Wq, meta = ops.prefilter_pack_w(W, bias)
 lib = _lib.load()
 lib.qsae_debug_set_prefilter_tile.argtypes = [C.c_int]
 lib.qsae_debug_set_xstat_rot.argtypes = [C.c_int]
+lib.qsae_debug_set_refine_ablate.argtypes = [C.c_int]
 
 VARIANTS = [(True, 2, 2), (False, 2, 2), (False, 2, 0), (False, 2, 1), (False, 2, 5), (False, 2, 8), (False, 2, 17),
             (False, 11, 2), (False, 11, 0), (False, 0, 0)]
@@ -32,7 +33,8 @@ res = {}
 for rnd in range(3):
     for dense, tile, rot in VARIANTS:
         lib.qsae_debug_set_prefilter_tile(tile)
-        lib.qsae_debug_set_xstat_rot(rot)
+        lib.qsae_debug_set_xstat_rot(rot % 10)
+        lib.qsae_debug_set_refine_ablate(rot // 10)      # rot = 10 * refine ablation + rotation
         ops.encode_topk_prefilter(x, W, bias, Wq, meta, k, want_dense=dense)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,11 +45,12 @@ for rnd in range(3):
         e1.record(); e1.synchronize()
         ops.sweep_timing(False)
         ms, n, frac = ops.sweep_timing_collect(H)
-        res.setdefault((dense, tile, rot), []).append((ms, e0.elapsed_time(e1) / 3))
+        res.setdefault((dense, tile, rot), []).append((ms, e0.elapsed_time(e1) / 3, lib.qsae_debug_last_flagged()))
 lib.qsae_debug_set_prefilter_tile(2)
 lib.qsae_debug_set_xstat_rot(2)
+lib.qsae_debug_set_refine_ablate(0)
 for (dense, tile, rot), ts in res.items():
     ms = sorted(t[0] for t in ts)[len(ts) // 2]
     tot = sorted(t[1] for t in ts)[len(ts) // 2]
     print(json.dumps(dict(dense_output=dense, tile=tile, rot=rot, sweep_ms=round(ms, 3), total_ms=round(tot, 3),
-                          sweep_fp16_tflops=round(frac * 2.0 * B * D * H / ms / 1e9, 1))), flush=True)
+                          flagged_rows=ts[-1][2], sweep_fp16_tflops=round(frac * 2.0 * B * D * H / ms / 1e9, 1))), flush=True)
