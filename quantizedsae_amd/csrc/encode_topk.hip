@@ -40,6 +40,7 @@ constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
+static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
 static unsigned long long* g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
 static int g_ref_ablate = 0;        // timing experiments on the refine kernel (results wrong when non-zero)
@@ -838,6 +839,10 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     // zero-fill their own blocks in the epilogue instead and the survivors are scattered in afterwards.
     const bool xstat = g_pref_tile == 2 && xstat_supported(D, H - P, P) && H % 4 == 0;
     float* fused_fill = xstat ? nullptr : dense;
+    // activation-stationary sweep: it also zero-fills the dense latent (all H columns, spread over its stages)
+    const int xs_stages = (H - P) / kXsHT;
+    const int fill_cw = xs_stages > 0 ? (32 * (H / 256) + xs_stages - 1) / xs_stages : 0;   // 1-KiB pieces per wave and stage
+    const bool fill_in_sweep = xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
     // 1. fp16 copy of the batch + per-row scale and error margin
     hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
     QSAE_LAUNCH_CHECK();
@@ -868,7 +873,7 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         }
         if (xstat) {
             XsArgs xa{xq + 0, Wq + static_cast<size_t>(P) * D, bias ? bias + P : nullptr, tau, margin, inv, cand, cnt,
-                      B, H - P, kCandCap, P, g_xstat_rot, g_xstat_stamps};
+                      B, H - P, kCandCap, P, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H, fill_cw};
             rc = launch_xstat(D, xa, s, g_xstat_ablate);
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
@@ -902,8 +907,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     // 6. flagged rows through the exact unfused kernels
     rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false);
     if (rc != QSAE_OK) return rc;
-    if (dense) return xstat ? densify_rows(idx, val, B, k, H, dense, dense_ld, s)
-                            : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
+    if (dense) return (xstat && !fill_in_sweep) ? densify_rows(idx, val, B, k, H, dense, dense_ld, s)
+                                                : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
 }
 
@@ -955,6 +960,8 @@ extern "C" int qsae_debug_set_refine_ablate(int v) {
 extern "C" int qsae_debug_last_flagged() { return g_last_flagged; }
 
 extern "C" int qsae_debug_set_xstat_rot(int rot) {
+    g_fill_in_sweep = rot >= 100 ? 0 : 1;                    // rot >= 100: separate fill pass (timing comparison)
+    rot %= 100;
     g_xstat_rot = rot;
     return QSAE_OK;
 }

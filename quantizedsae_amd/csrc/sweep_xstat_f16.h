@@ -44,6 +44,10 @@ struct XsArgs {
     int B, Hs, cap, hidden_offset;
     int rot_mul;             // row rotation of the DMA order per workgroup (see issue())
     unsigned long long* stamps;   // ABL == 5: per-wave phase cycle totals [wg][wave][8]
+    float* dense;            // optional [B][dense_ld] dense latent: zero-filled here, under the MFMA-bound sweep
+    long long dense_ld;
+    int H;                   // columns of the dense latent (all of them are filled, not only the swept ones)
+    int fill_cw;             // 1-KiB pieces (256 columns of one row) a wave fills per stage
 };
 
 template <int KB, int ABL = 0>   // k-blocks of 16 halves: D = 16 * KB; ABL: timing ablations (results wrong)
@@ -163,9 +167,25 @@ sweep_xstat_f16_kernel(XsArgs a) {
             const int n_other = __shfl_xor(nrec, 32, 64);
             int pos = count + (lane_half ? (n_other < kXsSlots ? n_other : kXsSlots) : 0);
             const int mine = nrec < kXsSlots ? nrec : kXsSlots;
+            // record slots by hand-written ds_reads: in front of a compiler-generated LDS read the compiler
+            // drains the vector-memory queue (it cannot know the slots never alias an LDS-DMA in flight),
+            // which here would wait for the acknowledgement of the previous stage's fill stores
+            static_assert(kXsSlots == 6, "the asm below reads six slots");
+            unsigned long long rr[kXsSlots];
+            asm volatile("ds_read_b64 %0, %6\n\t"
+                         "ds_read_b64 %1, %6 offset:512\n\t"
+                         "ds_read_b64 %2, %6 offset:1024\n\t"
+                         "ds_read_b64 %3, %6 offset:1536\n\t"
+                         "ds_read_b64 %4, %6 offset:2048\n\t"
+                         "ds_read_b64 %5, %6 offset:2560\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5])
+                         : "v"(ring_addr)
+                         : "memory");
             uint2 rec[kXsSlots];
 #pragma unroll
-            for (int j = 0; j < kXsSlots; ++j) rec[j] = *reinterpret_cast<const uint2*>(my_ring + j * 512);
+            for (int j = 0; j < kXsSlots; ++j)
+                rec[j] = make_uint2(static_cast<unsigned>(rr[j]), static_cast<unsigned>(rr[j] >> 32));
 #pragma unroll
             for (int j = 0; j < kXsSlots; ++j) {
                 if (j < mine && row_ok && ABL != 3 && pos + j < a.cap)
@@ -204,6 +224,63 @@ sweep_xstat_f16_kernel(XsArgs a) {
         const char* bb = bias_lds + (st % 3) * BIAS_BYTES + 16 * lane_half + mt * 128;
 #pragma unroll
         for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bb + 32 * g);
+    };
+
+    // ---- dense latent zero-fill -----------------------------------------------------------------------
+    // The reference returns latent * mask as a dense [B, H] tensor (sae/binary.py:96-99): 99.8 % zeros, 8 GiB
+    // per batch.  This kernel is bound by instruction issue and leaves HBM idle, so the zeros are written
+    // here: at the top of every stage (before the DMA, so the stage's vmcnt(0) also retires them a whole
+    // stage later) each wave writes `fill_quota` pieces of 1 KiB -- 256 consecutive columns of one of its
+    // 32 rows per store instruction, walking row after row (fully coalesced lines, one sequential stream
+    // per wave).  The k survivors are scattered in by the caller afterwards.
+    // Contiguous latent (ld == H): the workgroup's 256 rows are one block of memory and the eight waves
+    // write adjacent runs of it every stage (one sequential stream per workgroup); otherwise each wave walks
+    // its own 32 rows.
+    const int fill_ppr = a.H / 256;                          // pieces per row
+    const bool fill_linear = a.dense_ld == a.H;
+    const long long wg_row0 = static_cast<long long>(blockIdx.x) * kXsRows;
+    const long long fill_row0 = wg_row0 + (fill_linear ? 0 : wave * 32);
+    const long long rows_here = a.B - fill_row0 < (fill_linear ? kXsRows : 32) ? a.B - fill_row0 : (fill_linear ? kXsRows : 32);
+    const long long fill_total = (rows_here > 0 ? rows_here : 0) * fill_ppr;      // pieces this wave's sequence covers
+    long long fill_next = fill_linear ? static_cast<long long>(wave) * a.fill_cw : 0;   // next piece (wave-uniform)
+    const long long fill_step = fill_linear ? static_cast<long long>(kXsWaves - 1) * a.fill_cw : 0;
+    auto fill = [&]() -> int {                               // returns the number of store instructions issued
+        int issued = 0;
+        if (a.dense) {
+            int r = static_cast<int>(fill_next) / fill_ppr, c = static_cast<int>(fill_next) - r * fill_ppr;
+            for (int i = 0; i < a.fill_cw; ++i, ++fill_next) {
+                if (fill_next < fill_total) {
+                    float* base = a.dense + (fill_row0 + r) * a.dense_ld + c * 256;             // wave-uniform
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(base) + lane);   // streaming: keep W in L2
+                    ++issued;
+                }
+                if (++c == fill_ppr) { c = 0; ++r; }
+            }
+            fill_next += fill_step;                          // linear mode: skip the other waves' runs
+        }
+        return issued;
+    };
+    // vmcnt retires loads, stores and LDS-DMA together in issue order (MI355X guide, "s_waitcnt vmcnt(N)"):
+    // the fill stores are the youngest operations of a stage, so waiting for all but them retires the DMA
+    // without waiting for the stores' acknowledgement (they get the whole next stage for that).
+    auto wait_all_but = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
     };
 
     // ---- main loop ---------------------------------------------------------------------------------------
@@ -269,6 +346,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
         flush();                                             // older than the DMA issued next
         stamp(0);
         if (ld < nstages) issue();                           // stage s+1 -> the buffer read during stage s-1
+        const int nfill = fill();                            // the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
         tile_pass(sbase, 0, s > 0, 1, s - 1);
@@ -276,11 +354,12 @@ sweep_xstat_f16_kernel(XsArgs a) {
         tile_pass(sbase, 1, true, 0, s);
         stamp(3);
         // retire stage s+1 (for every wave) before anyone reads it; also frees this stage's buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_all_but(nfill);
         stamp(4);
         __builtin_amdgcn_s_barrier();
         stamp(5);
     }
+    while (a.dense && fill_next < fill_total) (void)fill();  // (quota * stages covers the block; safety net)
     if (ABL >= 5) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }
     if (ABL >= 5 && a.stamps && lane == 0) {
 #pragma unroll
