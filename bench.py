@@ -33,6 +33,7 @@ FLOPS_PER_ROW_ENCODER = 2 * D * H                       # the dominant kernel (S
 FLOPS_PER_ROW = 2 * D * H + 2 * K_TOP * D               # 33 620 992 algorithmic FLOP per row
 BYTES_PER_ROW_DENSE = 4 * D + 4 * H + 4 * D             # 135 168 B per row, dense-latent return
 PEAK_FP32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBPS = 8000.0                                  # HBM3E, MI355X_MICROARCH.md
 PEAK_FP16_MFMA_TFLOPS = 2500.0                          # dense (the ~5 PF headline figure includes 2:1 sparsity)
 
 
@@ -197,9 +198,10 @@ def main():
         if path_used == "prefilter" and sweep_n:
             enc_ms, peak = sweep_ms, PEAK_FP16_MFMA_TFLOPS
             achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
-            kname = (f"gemm_nt_f32_dma_kernel<EpiFilter<256,128,4,2,APPROX>, HALF> (fp16 MFMA prefilter sweep "
-                     f"{B}x512 @ 512x{int(round(H * sweep_frac))}, threshold filter + fused zero-fill of the dense latent)")
-            tkey = "sweep_dma_fp16"
+            kname = (f"sweep_xstat_f16_kernel<32> (fp16 MFMA candidate sweep {B}x512 @ 512x{int(round(H * sweep_frac))}: "
+                     "activation panel stationary in registers, weights streamed once per workgroup, threshold filter in "
+                     "the MFMA shadows, plus the zero-fill of the dense [B,32768] latent)")
+            tkey = "sweep_xstat_f16"
         elif sweep_n:
             enc_ms, peak = sweep_ms, PEAK_FP32_MFMA_TFLOPS
             achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
@@ -245,6 +247,12 @@ def main():
                          "traffic": pmc_traffic(tkey) if (tkey and B == ROWS_PER_GPU) else None},
             "fp32_only_path": fp32_ref,
         }
+        if path_used == "prefilter" and sweep_n and enc_ms:
+            # the same launch also writes the dense latent's zeros: its second resource, quoted beside the first
+            fill_gbps = 4.0 * B * H / (enc_ms * 1e-3) / 1e9
+            out["roofline"]["also"] = {"bound": "hbm", "what": "dense-latent zero-fill carried by the same launch",
+                                       "achieved": fill_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                       "frac": fill_gbps / PEAK_HBM_GBPS}
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             try:

@@ -40,6 +40,7 @@ constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
+static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
 static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
 static unsigned long long* g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
@@ -851,9 +852,16 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     const float* wq_w = reinterpret_cast<const float*>(Wq);
     // 2. approximate pilot block [B][P] (activation rows on registers, hidden units on lanes)
     {
-        using EpiP = EpiApproxDense<256, 128, 4, 2>;
-        typename EpiP::Args ep{inv, bias, pilot, P};
-        int rc = launch_gemm_dma<EpiP, 256, 128, true>(xq_w, B, wq_w, P, Kw, ep, s, /*sweep=*/8);
+        int rc;
+        if (g_pilot_tile == 0 && P % 256 == 0) {
+            using EpiP = EpiApproxDense<256, 256, 4, 2>;
+            typename EpiP::Args ep{inv, bias, pilot, P};
+            rc = launch_gemm_dma<EpiP, 256, 256, true, 2>(xq_w, B, wq_w, P, Kw, ep, s, /*sweep=*/8);
+        } else {
+            using EpiP = EpiApproxDense<256, 128, 4, 2>;
+            typename EpiP::Args ep{inv, bias, pilot, P};
+            rc = launch_gemm_dma<EpiP, 256, 128, true>(xq_w, B, wq_w, P, Kw, ep, s, /*sweep=*/8);
+        }
         if (rc != QSAE_OK) return rc;
     }
     // 3. tau~ = j-th largest approximate pilot value; seeds = pilot elements >= tau~ - 2 eps
@@ -960,6 +968,8 @@ extern "C" int qsae_debug_set_refine_ablate(int v) {
 extern "C" int qsae_debug_last_flagged() { return g_last_flagged; }
 
 extern "C" int qsae_debug_set_xstat_rot(int rot) {
+    g_pilot_tile = rot >= 1000 ? 1 : 0;                      // rot >= 1000: 256 x 128 pilot tile (timing comparison)
+    rot %= 1000;
     g_fill_in_sweep = rot >= 100 ? 0 : 1;                    // rot >= 100: separate fill pass (timing comparison)
     rot %= 100;
     g_xstat_rot = rot;

@@ -33,7 +33,7 @@ res = {}
 for rnd in range(3):
     for dense, tile, rot in VARIANTS:
         lib.qsae_debug_set_prefilter_tile(tile)
-        lib.qsae_debug_set_xstat_rot(rot % 10 + 100 * (rot // 100))   # rot >= 100: separate fill pass
+        lib.qsae_debug_set_xstat_rot(rot % 10 + 100 * (rot // 100))   # rot >= 100: separate fill pass, >= 1000: old pilot tile
         lib.qsae_debug_set_refine_ablate((rot % 100) // 10)          # tens digit: refine ablation
         ops.encode_topk_prefilter(x, W, bias, Wq, meta, k, want_dense=dense)
         torch.cuda.synchronize()
