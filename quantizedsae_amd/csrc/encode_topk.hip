@@ -306,12 +306,15 @@ gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, 
 
 __global__ void __launch_bounds__(256)
 scatter_topk_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sval, const int* __restrict__ rows,
-                    int n, int k, int32_t* __restrict__ idx, float* __restrict__ val) {
+                    int n, int k, int32_t* __restrict__ idx, float* __restrict__ val, float* __restrict__ dense,
+                    int64_t dense_ld, int H) {
     const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= static_cast<long long>(n) * k) return;
     const int r = static_cast<int>(gid / k), j = static_cast<int>(gid % k);
     idx[static_cast<long long>(rows[r]) * k + j] = sidx[gid];
     val[static_cast<long long>(rows[r]) * k + j] = sval[gid];
+    // optional: the row's entries of an already zero-filled dense latent
+    if (dense && sidx[gid] >= 0 && sidx[gid] < H) dense[static_cast<long long>(rows[r]) * dense_ld + sidx[gid]] = sval[gid];
 }
 
 static int dense_latent(const float* x, const float* W, const float* bias, int B, int D, int H, float* out, int64_t ld,
@@ -337,7 +340,7 @@ static int run_chunked(const float* x, const float* W, const float* bias, int B,
 // 4-byte read-back, then the unfused exact kernels on exactly those rows.
 static int run_flagged_rows(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
                             int32_t* idx, float* val, char* ws, const FusedLayout& L, qsae_stream_t stream,
-                            bool kperm) {
+                            bool kperm, float* dense = nullptr, int64_t dense_ld = 0) {
     hipStream_t s = as_stream(stream);
     int* flags = reinterpret_cast<int*>(ws + L.flags);
     int nflag = 0;
@@ -362,7 +365,7 @@ static int run_flagged_rows(const float* x, const float* W, const float* bias, i
         if (rc != QSAE_OK) return rc;
         const long long tk = static_cast<long long>(n) * k;
         hipLaunchKernelGGL(scatter_topk_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx, fval,
-                           rows, n, k, idx, val);
+                           rows, n, k, idx, val, dense, dense_ld, H);
         QSAE_LAUNCH_CHECK();
     }
     return QSAE_OK;
@@ -622,7 +625,8 @@ __global__ void __launch_bounds__(64 * kRefWaves)
 refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
                    const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
-                   float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps) {
+                   float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps,
+                   float* __restrict__ dense, int64_t dense_ld) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
     // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -808,8 +812,11 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         int rank = 0;
         for (int i = 0; i < m; ++i) rank += (ekey[i] > mine) ? 1 : 0;
         if (rank < k) {
-            idx_out[static_cast<int64_t>(b) * k + rank] = static_cast<int32_t>(key_index(mine));
-            val_out[static_cast<int64_t>(b) * k + rank] = reinterpret_cast<const float*>(hidx)[j];
+            const int32_t hi = static_cast<int32_t>(key_index(mine));
+            const float vv = reinterpret_cast<const float*>(hidx)[j];
+            idx_out[static_cast<int64_t>(b) * k + rank] = hi;
+            val_out[static_cast<int64_t>(b) * k + rank] = vv;
+            if (dense) dense[static_cast<int64_t>(b) * dense_ld + hi] = vv;      // latent * mask; zeros are already there
         }
     }
     stamp(5);
@@ -909,14 +916,16 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
             configured = true;
         }
         hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
-                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps);
+                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps, fill_in_sweep ? dense : nullptr, dense_ld);
     }
     QSAE_LAUNCH_CHECK();
     // 6. flagged rows through the exact unfused kernels
-    rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false);
+    // (with the zeros written by the sweep, refine and the fallback write the survivors straight into the latent)
+    rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false,
+                          fill_in_sweep ? dense : nullptr, dense_ld);
     if (rc != QSAE_OK) return rc;
-    if (dense) return (xstat && !fill_in_sweep) ? densify_rows(idx, val, B, k, H, dense, dense_ld, s)
-                                                : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
+    if (dense && !fill_in_sweep)
+        return xstat ? densify_rows(idx, val, B, k, H, dense, dense_ld, s) : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
 }
 

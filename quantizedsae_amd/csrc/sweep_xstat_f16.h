@@ -350,6 +350,9 @@ sweep_xstat_f16_kernel(XsArgs a) {
         stamp(1);
         const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
         tile_pass(sbase, 0, s > 0, 1, s - 1);
+        // a lane that already holds four records could overflow its six slots in the second pass: flush now
+        // (rare; the stores are younger than the stage's DMA, which only makes the wait below stricter)
+        if (__builtin_amdgcn_ballot_w64(nrec > kXsSlots - 3) != 0ull) flush();
         stamp(2);
         tile_pass(sbase, 1, true, 0, s);
         stamp(3);

@@ -201,8 +201,9 @@ def prefilter_supported(B: int, D: int, H: int, k: int) -> bool:
 
 
 def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
-                          meta: torch.Tensor, k: int, want_dense: bool = True):
-    """fp16-prefiltered encoder + exact top-k (+ dense latent): results identical to encode_topk_latent."""
+                          meta: torch.Tensor, k: int, want_dense: bool = True, dense_out: Optional[torch.Tensor] = None):
+    """fp16-prefiltered encoder + exact top-k (+ dense latent): results identical to encode_topk_latent.
+    ``dense_out``: optional [B, >=H] fp32 buffer (row stride a multiple of 4) that receives the dense latent."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
     B, D = x.shape
     H = W.shape[0]
@@ -214,10 +215,17 @@ def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     ws = _workspace(x.device, need)
     idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
-    dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
+    if dense_out is not None:
+        _dev(dense_out, "dense_out", torch.float32)
+        if dense_out.dim() != 2 or dense_out.shape[0] != B or dense_out.shape[1] < H or dense_out.stride(1) != 1:
+            raise ValueError("dense_out must be a [B, >=H] fp32 tensor with unit column stride")
+        dense, ld = dense_out, dense_out.stride(0)
+    else:
+        dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
+        ld = H
     check(lib.qsae_encode_topk_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(idx), _p(val),
-                                         _p(dense), H, _p(ws), ws.numel(), _stream()))
-    return idx, val, dense
+                                         _p(dense), ld, _p(ws), ws.numel(), _stream()))
+    return idx, val, (dense[:, :H] if dense_out is not None else dense)
 
 
 def densify(idx: torch.Tensor, val: torch.Tensor, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

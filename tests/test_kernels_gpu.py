@@ -429,6 +429,44 @@ def test_prefilter_equals_oracle(fused_path, B, D, H, k):
     assert none is None and np.array_equal(host(idx2), w2[0]) and np.array_equal(host(val2), w2[1])
 
 
+@pytest.mark.parametrize("B,D,H,k", [(515, 256, 8192, 16), (700, 128, 4096, 8), (257, 512, 4096, 65), (40, 128, 4096, 8)])
+def test_prefilter_stationary_sweep_shapes(fused_path, B, D, H, k):
+    """The activation-stationary sweep (D in {128, 256, 512}) on ragged batches, biased and unbiased."""
+    ops = _ops()
+    x = S.activations(98, B, D)
+    W = S.xavier_uniform(98, H, D, stream=1)
+    bias = S.normal(98, (H,), stream=3, std=0.1)
+    assert ops.prefilter_supported(B, D, H, k)
+    idx, val, dense = _prefilter(ops, x, W, bias, k)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
+
+
+def test_prefilter_stationary_sweep_strided_dense_and_degenerate_rows(fused_path):
+    """D = 512 (the stationary sweep): dense latent into a strided buffer whose padding must stay untouched;
+    rows that tie everywhere, hold inf / NaN, or flood their candidate slots take the exact fallback."""
+    ops = _ops()
+    B, D, H, k = 530, 512, 8192, 65
+    x = S.activations(99, B, D)
+    W = S.xavier_uniform(99, H, D, stream=1)
+    bias = S.normal(99, (H,), stream=3, std=0.02)
+    x[3] = 0.0                                             # latent == bias: dense ties at the top are possible
+    x[10, 5] = np.inf
+    x[11, 7] = np.nan
+    x[20] *= 1e-30                                         # latents ~ bias: thousands of near-equal candidates
+    Wq, meta = ops.prefilter_pack_w(dev(W), dev(bias))
+    buf = torch.full((B, H + 64), 7.0, dtype=torch.float32, device=DEV)
+    idx, val, dense = ops.encode_topk_prefilter(dev(x), dev(W), dev(bias), Wq, meta, k, dense_out=buf)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    ok = np.ones(B, bool); ok[[10, 11]] = False
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val)[ok].view(np.uint32), want_val[ok].view(np.uint32))
+    assert np.array_equal(host(dense)[ok], oracle.densify(want_idx, want_val, H)[ok])
+    assert bool((buf[:, H:] == 7.0).all())                 # the fill respects the row stride
+
+
 def test_prefilter_error_bound_holds_with_margin(fused_path):
     """max |approx - exact chain| over the pilot block stays far below the eps_b the selection relies on
     (inputs with outliers, tiny and huge scales)."""
