@@ -30,7 +30,26 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
     const size_t n4 = n / 4;
     double acc = 0.0;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    // four independent 16-byte loads per operand in flight per thread (the loop is latency-bound otherwise)
+    size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    double acc1 = 0.0;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = reinterpret_cast<const f32x4*>(r)[i + u * stride];
+            b[u] = reinterpret_cast<const f32x4*>(x)[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = a[u][j] - b[u][j];
+                if (u & 1) acc1 += static_cast<double>(d * d);
+                else acc += static_cast<double>(d * d);
+            }
+    }
+    for (; i < n4; i += stride) {
         const f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
         const f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
@@ -39,6 +58,7 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
             acc += static_cast<double>(d * d);
         }
     }
+    acc += acc1;
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         const float d = r[i] - x[i];
@@ -172,7 +192,7 @@ extern "C" int qsae_sq_err_sum(const float* recon, const float* x, size_t n, dou
     QSAE_CHECK_ARG(aligned16(recon) && aligned16(x), "recon and x must be 16-byte aligned");
     const size_t n4 = n / 4;
     size_t blocks = (n4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(sq_err_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), recon, x,
                        n, sum);
