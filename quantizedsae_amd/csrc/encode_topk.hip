@@ -28,7 +28,7 @@ namespace qsae {
 
 int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
                        float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s,
-                       const float* margin = nullptr);
+                       const float* margin = nullptr, int stride = 0);
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 int densify_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
@@ -456,7 +456,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
 //   exact top-k satisfies s^ >= t~ - 2 eps_b; those survivors (~90 of 32768) are re-evaluated with the
 //   exact chain and ranked exactly.  tests/test_kernels_gpu.py measures max|s^ - s| / eps_b on hardware.
 struct PrefLayout {
-    size_t xq, inv, margin, total_extra;
+    size_t xq, inv, margin, cnt_parts, total_extra;
 };
 static PrefLayout pref_layout(int B, int D, size_t base) {
     PrefLayout P;
@@ -464,6 +464,7 @@ static PrefLayout pref_layout(int B, int D, size_t base) {
     P.xq = off;     off = align_up(off + static_cast<size_t>(B) * D * 2, 256);
     P.inv = off;    off = align_up(off + static_cast<size_t>(B) * 4, 256);
     P.margin = off; off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    P.cnt_parts = off; off = align_up(off + static_cast<size_t>(B) * 4 * 7, 256);    // list-segment counters of parts 1..7
     P.total_extra = off;
     return P;
 }
@@ -626,7 +627,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                    const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
                    float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps,
-                   float* __restrict__ dense, int64_t dense_ld) {
+                   float* __restrict__ dense, int64_t dense_ld, int parts, const int* __restrict__ cnt_parts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
     // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -655,10 +656,18 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     // row scalars through the constant address space (written by earlier launches only): s_load, no VGPRs
     typedef const __attribute__((address_space(4))) int* cint_t;
     typedef const __attribute__((address_space(4))) float* cflt_t;
-    const int n = ((cint_t)cnt)[b];
+    // the row's list is `parts` segments of cap/parts entries (one per hidden-range part of the sweep)
+    const int cap_part = cap / parts;
+    int n = 0;
+    bool seg_overflow = false;
+    for (int p = 0; p < parts; ++p) {
+        const int np = p == 0 ? ((cint_t)cnt)[b] : ((cint_t)cnt_parts)[static_cast<size_t>(p - 1) * B + b];
+        seg_overflow |= np > cap_part;
+        n += np;
+    }
     const float tau_b = ((cflt_t)tau)[b];
     const float margin_b = ((cflt_t)margin)[b];
-    if (n < k || n > cap) { flag_row(); return; }
+    if (n < k || seg_overflow) { flag_row(); return; }
     // ---- candidate list -> LDS (the W tile's space: value keys [1024] | hidden indices [1024]) ----------
     // Keys live in LDS, not in 16 register slots per lane: short loops instead of 4000 lines of unrolled
     // select code, and the registers go to the W staging sets.
@@ -669,20 +678,23 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     static_assert(2 * kCandCap * 4 <= 64 * kRefTileStride * 4, "candidate keys must fit the W tile");
     bool any_nan = false;
     uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
-    for (int s = 0; s < nslots; ++s) {
-        const int i = s * 64 + lane;
-        uint32_t kk = 0u;
-        if (i < n) {
-            const uint2 c = list[i];
+    int filled = 0;                                                    // entries staged so far (wave-uniform)
+    for (int p = 0; p < parts; ++p) {
+        const int np = p == 0 ? ((cint_t)cnt)[b] : ((cint_t)cnt_parts)[static_cast<size_t>(p - 1) * B + b];
+        const uint2* seg = list + p * cap_part;
+        for (int i = lane; i < np; i += 64) {
+            const uint2 c = seg[i];
             const float v = __uint_as_float(c.x);
-            kk = mono_key(v);
+            const uint32_t kk = mono_key(v);
             any_nan |= (v != v);
             all_or |= kk;
             all_and &= kk;
-            lidx[i] = c.y;
+            lkey[filled + i] = kk;
+            lidx[filled + i] = c.y;
         }
-        lkey[i] = kk;
+        filled += np;
     }
+    if (n + lane < nslots * 64) lkey[n + lane] = 0u;                   // padding of the last slot
     if (__any(any_nan)) { flag_row(); return; }                        // NaN latents: let the exact path rank them
     lds_handoff();
     stamp(0);
@@ -851,6 +863,11 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     const int xs_stages = (H - P) / kXsHT;
     const int fill_cw = xs_stages > 0 ? (32 * (H / 256) + xs_stages - 1) / xs_stages : 0;   // 1-KiB pieces per wave and stage
     const bool fill_in_sweep = xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
+    // small batches: the hidden range of the sweep is split over `parts` workgroup columns, each with its own
+    // segment of every row's candidate list
+    const int parts = xstat ? xstat_parts(B, H - P, kCandCap) : 1;
+    const int cap_part = kCandCap / parts;
+    int* cnt_parts = reinterpret_cast<int*>(ws + PL.cnt_parts);
     // 1. fp16 copy of the batch + per-row scale and error margin
     hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
     QSAE_LAUNCH_CHECK();
@@ -873,8 +890,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     }
     // 3. tau~ = j-th largest approximate pilot value; seeds = pilot elements >= tau~ - 2 eps
     const int j = kPilotRank < P ? kPilotRank : P;
-    int rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, fused_fill, dense_ld, s,
-                                margin);
+    int rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, cap_part, fused_fill, dense_ld, s,
+                                margin, kCandCap);
     if (rc != QSAE_OK) return rc;
     // 4. fp16 sweep of the remaining hidden units with the threshold filter (tau~ - 2 eps)
     {
@@ -888,7 +905,7 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         }
         if (xstat) {
             XsArgs xa{xq + 0, Wq + static_cast<size_t>(P) * D, bias ? bias + P : nullptr, tau, margin, inv, cand, cnt,
-                      B, H - P, kCandCap, P, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H, fill_cw};
+                      B, H - P, kCandCap, P, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H, fill_cw, parts, cnt_parts};
             rc = launch_xstat(D, xa, s, g_xstat_ablate);
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
@@ -916,7 +933,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
             configured = true;
         }
         hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
-                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps, fill_in_sweep ? dense : nullptr, dense_ld);
+                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps,
+                           fill_in_sweep ? dense : nullptr, dense_ld, parts, cnt_parts);
     }
     QSAE_LAUNCH_CHECK();
     // 6. flagged rows through the exact unfused kernels

@@ -48,6 +48,8 @@ struct XsArgs {
     long long dense_ld;
     int H;                   // columns of the dense latent (all of them are filled, not only the swept ones)
     int fill_cw;             // 1-KiB pieces (256 columns of one row) a wave fills per stage
+    int parts;               // hidden-range split (gridDim.y): part p sweeps stages [p*n/parts, (p+1)*n/parts),
+    int* cnt_parts;          //   appends to the row's list segment [p*cap/parts, ...) and counts in cnt_parts[(p-1)*B + row]
 };
 
 template <int KB, int ABL = 0>   // k-blocks of 16 halves: D = 16 * KB; ABL: timing ablations (results wrong)
@@ -106,8 +108,15 @@ sweep_xstat_f16_kernel(XsArgs a) {
     char* bias_lds = xs_smem + BIAS_BASE;
     char* my_ring = xs_smem + RING_BASE + wave * RING_WAVE + lane * 8;     // this lane's slot 0
     if (!a.bias && tid < 3 * kXsHT) reinterpret_cast<float*>(bias_lds)[tid] = 0.f;   // no bias: the copies stay zero
-    const int nstages = a.Hs / kXsHT;
-    int ld = 0;                                              // next stage to issue
+    // Small batches have fewer 256-row panels than the chip has CUs: the hidden range is then split over
+    // gridDim.y parts, each with its own segment of every row's candidate list and its own counter.
+    const int part = blockIdx.y;
+    const int all_stages = a.Hs / kXsHT;
+    const int s_begin = static_cast<int>(static_cast<long long>(part) * all_stages / a.parts);
+    const int nstages = static_cast<int>(static_cast<long long>(part + 1) * all_stages / a.parts);   // end (absolute)
+    const int cap_part = a.cap / a.parts;
+    int* my_cnt = part == 0 ? a.cnt : a.cnt_parts + static_cast<size_t>(part - 1) * a.B;
+    int ld = s_begin;                                        // next stage to issue (absolute stage index)
     auto issue = [&]() {
         char* dst = xs_smem + (ld % kXsStages) * STAGE_BYTES;
         const char* sb = reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(ld) * STAGE_BYTES;
@@ -121,7 +130,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
                                              (lptr_t)(bias_lds + (ld % 3) * BIAS_BYTES), 16, 0, 0);
         ++ld;
     };
-    if (nstages > 0) issue();
+    if (ld < nstages) issue();
     // Make the compiler retire its own loads (x fragments, threshold, scale) HERE: it cannot see the asm
     // waits below, and a load still pending in its model at the loop header costs a vmcnt(0) per stage.
     float thr_r = thr, inv_r = inv;
@@ -157,8 +166,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // other overflowing row.
     f32x16 acc[MT];
     int nrec = 0;                                            // records in this lane's slots
-    int count = row_ok ? a.cnt[crow] : 0;                    // the row's list length (equal in both lanes)
-    uint2* list = a.cand + static_cast<int64_t>(crow) * a.cap;
+    int count = (row_ok && part == 0) ? a.cnt[crow] : 0;     // this part's segment length (equal in both lanes)
+    uint2* list = a.cand + static_cast<int64_t>(crow) * a.cap + part * cap_part;
     typedef __attribute__((address_space(3))) char* lds_char_t;
     const unsigned ring_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char_t)my_ring));   // LDS byte address
     auto flush = [&]() {
@@ -188,11 +197,11 @@ sweep_xstat_f16_kernel(XsArgs a) {
                 rec[j] = make_uint2(static_cast<unsigned>(rr[j]), static_cast<unsigned>(rr[j] >> 32));
 #pragma unroll
             for (int j = 0; j < kXsSlots; ++j) {
-                if (j < mine && row_ok && ABL != 3 && pos + j < a.cap)
+                if (j < mine && row_ok && ABL != 3 && pos + j < cap_part)
                     list[pos + j] = make_uint2(rec[j].x, rec[j].y & 0x07FFFFFFu);
             }
             count += mine + (n_other < kXsSlots ? n_other : kXsSlots);
-            if (nrec > kXsSlots || n_other > kXsSlots) count = a.cap + 1;     // lost records: exact fallback
+            if (nrec > kXsSlots || n_other > kXsSlots) count = cap_part + 1;  // lost records: exact fallback
             asm volatile("" ::: "memory");
             nrec = 0;
         }
@@ -241,8 +250,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const long long wg_row0 = static_cast<long long>(blockIdx.x) * kXsRows;
     const long long fill_row0 = wg_row0 + (fill_linear ? 0 : wave * 32);
     const long long rows_here = a.B - fill_row0 < (fill_linear ? kXsRows : 32) ? a.B - fill_row0 : (fill_linear ? kXsRows : 32);
-    const long long fill_total = (rows_here > 0 ? rows_here : 0) * fill_ppr;      // pieces this wave's sequence covers
-    long long fill_next = fill_linear ? static_cast<long long>(wave) * a.fill_cw : 0;   // next piece (wave-uniform)
+    // pieces this wave's sequence covers; with a split hidden range every part takes an equal share of them
+    const long long fill_all = (rows_here > 0 ? rows_here : 0) * fill_ppr;
+    const long long fill_begin = fill_all * part / a.parts, fill_total = fill_all * (part + 1) / a.parts;
+    long long fill_next = fill_begin + (fill_linear ? static_cast<long long>(wave) * a.fill_cw : 0);   // next piece (wave-uniform)
     const long long fill_step = fill_linear ? static_cast<long long>(kXsWaves - 1) * a.fill_cw : 0;
     auto fill = [&]() -> int {                               // returns the number of store instructions issued
         int issued = 0;
@@ -342,14 +353,14 @@ sweep_xstat_f16_kernel(XsArgs a) {
         acc[mt] = c;
     };
 #pragma unroll 1
-    for (int s = 0; s < nstages; ++s) {
+    for (int s = s_begin; s < nstages; ++s) {
         flush();                                             // older than the DMA issued next
         stamp(0);
         if (ld < nstages) issue();                           // stage s+1 -> the buffer read during stage s-1
         const int nfill = fill();                            // the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
-        tile_pass(sbase, 0, s > 0, 1, s - 1);
+        tile_pass(sbase, 0, s > s_begin, 1, s - 1);
         // a lane that already holds four records could overflow its six slots in the second pass: flush now
         // (rare; the stores are younger than the stage's DMA, which only makes the wait below stricter)
         if (__builtin_amdgcn_ballot_w64(nrec > kXsSlots - 3) != 0ull) flush();
@@ -368,7 +379,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * kXsWaves + wave) * 8 + i] = tacc[i];
     }
-    if (FILTER && nstages > 0) {
+    if (FILTER && nstages > s_begin) {
         f32x4 bq[4];
         load_bias(nstages - 1, 1, bq);
         const unsigned tag = stage_tag(nstages - 1);
@@ -376,12 +387,21 @@ sweep_xstat_f16_kernel(XsArgs a) {
         for (int q = 0; q < 16; ++q) filter_value(1, q, tag, bq[q >> 2]);
     }
     flush();
-    if (row_ok && lane_half == 0) a.cnt[row] = count;
+    if (row_ok && lane_half == 0) my_cnt[row] = count;
 }
 
 inline bool xstat_supported(int D, int Hs, int hidden_offset) {
     return (D == 512 || D == 256 || D == 128) && Hs > 0 && Hs % kXsHT == 0 && hidden_offset % 4 == 0 &&
            static_cast<int64_t>(hidden_offset) + Hs <= (1 << 27);      // 27-bit hidden index in a ring record
+}
+
+// hidden-range split for small batches: double while the grid stays within the chip's 256 CUs, the stage
+// count divides evenly and every part keeps a list segment of at least 128 entries
+inline int xstat_parts(int B, int Hs, int cap) {
+    const int wgs = (B + kXsRows - 1) / kXsRows, stages = Hs / kXsHT;
+    int parts = 1;
+    while (parts < 8 && wgs * parts * 2 <= 256 && stages % (parts * 2) == 0 && cap / (parts * 2) >= 128) parts *= 2;
+    return parts;
 }
 
 template <int KB, int ABL = 0>
@@ -395,7 +415,7 @@ inline int launch_xstat_one(const XsArgs& a, hipStream_t stream) {
                                      static_cast<int>(lds)));
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3((a.B + kXsRows - 1) / kXsRows), dim3(64 * kXsWaves), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((a.B + kXsRows - 1) / kXsRows, a.parts), dim3(64 * kXsWaves), lds, stream, a);
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }

@@ -43,7 +43,8 @@ struct PilotOut {
     float* tau;
     uint2* cand;
     int* cnt;
-    int cap;
+    int cap;             // entries of the row's list the seeds may use
+    int stride;          // entries between the lists of consecutive rows (>= cap)
     float* dense;        // optional: the row's first H (pilot) columns of the dense latent are zero-filled
     int64_t dense_ld;    //   here, on the way (the sweep zero-fills the rest, the survivors are scattered later)
     const float* margin; // optional [B]: candidates are the elements >= tau - margin[row] (approximate pilots)
@@ -190,7 +191,7 @@ topk_rows_kernel(float* __restrict__ latent, int64_t ld, int H, int k, int32_t* 
         if (tid == 0) { pilot.tau[blockIdx.x] = tf; sh.count = 0; }
         __syncthreads();
         const float tcut = pilot.margin ? tf - pilot.margin[blockIdx.x] : tf;
-        uint2* list = pilot.cand + static_cast<int64_t>(blockIdx.x) * pilot.cap;
+        uint2* list = pilot.cand + static_cast<int64_t>(blockIdx.x) * pilot.stride;
 #pragma unroll
         for (int i = 0; i < VPT4; ++i) {
             const int e = (i * kTopkThreads + tid) * 4;
@@ -246,8 +247,8 @@ static int launch_topk(float* latent, int64_t ld, int B, int H, int k, int32_t* 
 // shared by qsae_topk_rows and the pilot stage of qsae_encode_topk (encode_topk.hip)
 int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* idx, float* val, int zero_rest,
                        float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s,
-                       const float* margin) {
-    const PilotOut pilot{tau, cand, cnt, cap, dense, dense_ld, margin};
+                       const float* margin, int stride) {
+    const PilotOut pilot{tau, cand, cnt, cap, stride > 0 ? stride : cap, dense, dense_ld, margin};
     const int per_thread4 = (H + 1023) / 1024;
     if (per_thread4 <= 1) return launch_topk<1>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
     if (per_thread4 <= 2) return launch_topk<2>(latent, ld, B, H, k, idx, val, zero_rest, pilot, s);
@@ -273,5 +274,5 @@ extern "C" int qsae_topk_rows(float* latent, int64_t ld, int B, int H, int k, in
     QSAE_CHECK_SUPPORTED(H % 4 == 0 && ld % 4 == 0, "H and ld must be multiples of 4");
     QSAE_CHECK_ARG(aligned16(latent), "latent must be 16-byte aligned");
     return topk_rows_dispatch(latent, ld, B, H, k, idx, val, zero_rest, nullptr, nullptr, nullptr, 0, nullptr, 0,
-                              as_stream(stream), nullptr);
+                              as_stream(stream), nullptr, 0);
 }
