@@ -255,22 +255,30 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const long long fill_begin = fill_all * part / a.parts, fill_total = fill_all * (part + 1) / a.parts;
     long long fill_next = fill_begin + (fill_linear ? static_cast<long long>(wave) * a.fill_cw : 0);   // next piece (wave-uniform)
     const long long fill_step = fill_linear ? static_cast<long long>(kXsWaves - 1) * a.fill_cw : 0;
-    auto fill = [&]() -> int {                               // returns the number of store instructions issued
-        int issued = 0;
+    // One piece per call, at most a.fill_cw per stage; the calls sit between the MFMA groups of the stage
+    // (a burst of nine 1-KiB stores at the top of a stage overruns the write queues and stalls the wave).
+    int fill_left = 0, nfill = 0;                            // budget / store instructions issued this stage
+    int fill_r = 0, fill_c = 0;
+    auto fill_begin_stage = [&]() {
         if (a.dense) {
-            int r = static_cast<int>(fill_next) / fill_ppr, c = static_cast<int>(fill_next) - r * fill_ppr;
-            for (int i = 0; i < a.fill_cw; ++i, ++fill_next) {
-                if (fill_next < fill_total) {
-                    float* base = a.dense + (fill_row0 + r) * a.dense_ld + c * 256;             // wave-uniform
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(base) + lane);   // streaming: keep W in L2
-                    ++issued;
-                }
-                if (++c == fill_ppr) { c = 0; ++r; }
-            }
-            fill_next += fill_step;                          // linear mode: skip the other waves' runs
+            fill_left = a.fill_cw;
+            nfill = 0;
+            fill_r = static_cast<int>(fill_next) / fill_ppr;
+            fill_c = static_cast<int>(fill_next) - fill_r * fill_ppr;
         }
-        return issued;
+    };
+    auto fill_one = [&]() {
+        if (fill_left > 0) {                                 // wave-uniform
+            if (fill_next < fill_total) {
+                float* base = a.dense + (fill_row0 + fill_r) * a.dense_ld + fill_c * 256;      // wave-uniform
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(base) + lane);   // streaming: keep W in L2
+                ++nfill;
+            }
+            ++fill_next;
+            if (++fill_c == fill_ppr) { fill_c = 0; ++fill_r; }
+            if (--fill_left == 0) fill_next += fill_step;    // linear mode: skip the other waves' runs
+        }
     };
     // vmcnt retires loads, stores and LDS-DMA together in issue order (MI355X guide, "s_waitcnt vmcnt(N)"):
     // the fill stores are the youngest operations of a stage, so waiting for all but them retires the DMA
@@ -338,6 +346,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
 #pragma unroll
                 for (int u = 0; u < VPG; ++u) filter_value(fmt, (kb / 2) * VPG + u, tag, bq[((kb / 2) * VPG + u) >> 2]);
             }
+            fill_one();
             __builtin_amdgcn_sched_barrier(0);
             if (kb + 4 < KB) { w0 = rd(kb + 4); w1 = rd(kb + 5); }
             __builtin_amdgcn_sched_barrier(0);
@@ -357,7 +366,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
         flush();                                             // older than the DMA issued next
         stamp(0);
         if (ld < nstages) issue();                           // stage s+1 -> the buffer read during stage s-1
-        const int nfill = fill();                            // the youngest vector-memory operations of the stage
+        fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
         tile_pass(sbase, 0, s > s_begin, 1, s - 1);
@@ -367,13 +376,17 @@ sweep_xstat_f16_kernel(XsArgs a) {
         stamp(2);
         tile_pass(sbase, 1, true, 0, s);
         stamp(3);
+        while (fill_left > 0) fill_one();                    // (budgets beyond the 16 slots of a stage)
         // retire stage s+1 (for every wave) before anyone reads it; also frees this stage's buffer
         wait_all_but(nfill);
         stamp(4);
         __builtin_amdgcn_s_barrier();
         stamp(5);
     }
-    while (a.dense && fill_next < fill_total) (void)fill();  // (quota * stages covers the block; safety net)
+    while (a.dense && fill_next < fill_total) {              // (quota * stages covers the block; safety net)
+        fill_begin_stage();
+        while (fill_left > 0) fill_one();
+    }
     if (ABL >= 5) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }
     if (ABL >= 5 && a.stamps && lane == 0) {
 #pragma unroll
