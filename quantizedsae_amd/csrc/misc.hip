@@ -30,15 +30,17 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
     const size_t n4 = n / 4;
     double acc = 0.0;
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-    // four independent 16-byte loads per operand in flight per thread (the loop is latency-bound otherwise)
-    size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // a workgroup walks 16-KiB tiles (4 x 256 chunks of 16 bytes): four independent loads per operand in flight
+    // per thread, all inside one contiguous tile
+    const size_t tiles = n4 / 1024;
     double acc1 = 0.0;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t i0 = t * 1024 + threadIdx.x;
         f32x4 a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            a[u] = reinterpret_cast<const f32x4*>(r)[i + u * stride];
-            b[u] = reinterpret_cast<const f32x4*>(x)[i + u * stride];
+            a[u] = reinterpret_cast<const f32x4*>(r)[i0 + 256 * u];
+            b[u] = reinterpret_cast<const f32x4*>(x)[i0 + 256 * u];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -49,7 +51,7 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
                 else acc += static_cast<double>(d * d);
             }
     }
-    for (; i < n4; i += stride) {
+    for (size_t i = tiles * 1024 + static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const f32x4 a = reinterpret_cast<const f32x4*>(r)[i];
         const f32x4 b = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
@@ -64,8 +66,15 @@ sq_err_kernel(const float* __restrict__ r, const float* __restrict__ x, size_t n
         const float d = r[i] - x[i];
         acc += static_cast<double>(d * d);
     }
+    // one atomic per workgroup: tens of thousands of fp64 atomics on one address serialise (~12 ns each)
+    __shared__ double wave_sum[4];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(sum, acc);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+        if (t != 0.0) atomicAdd(sum, t);
+    }
 }
 
 // dst[r][8g + j/2 + 4*(j&1)] = src[r][8g + j]: every 8 consecutive k stored as [k0 k2 k4 k6 k1 k3 k5 k7],
@@ -191,8 +200,8 @@ extern "C" int qsae_sq_err_sum(const float* recon, const float* x, size_t n, dou
     QSAE_CHECK_ARG(recon && x && sum, "null pointer");
     QSAE_CHECK_ARG(aligned16(recon) && aligned16(x), "recon and x must be 16-byte aligned");
     const size_t n4 = n / 4;
-    size_t blocks = (n4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    size_t blocks = (n4 + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(sq_err_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), recon, x,
                        n, sum);
