@@ -193,6 +193,20 @@ int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, float thr, u
  * zeroes it).  scripts/analysis/dynamic_analysis.py:86-100. */
 int qsae_sq_err_sum(const float* recon, const float* x, size_t n, double* sum, qsae_stream_t stream);
 
+/* -- consumers of the sparse latent (scripts/analysis/dynamic_analysis.py:255-311, 314-440) ---------------- */
+/* counts[idx[b][j]] += 1 for every entry with val[b][j] > 0 (val == NULL: every entry): mask.sum(dim=0) of the
+ * reference's activation mask `latent > 0`, accumulated over calls (the caller zeroes counts[H], uint64). */
+int qsae_activation_counts(const int32_t* idx, const float* val, int B, int k, int H, unsigned long long* counts,
+                           qsae_stream_t stream);
+/* The same for bit-packed masks (`latent > 0.5` of the matryoshka / residual encoders): counts[32 w + j] += bit j
+ * of zbits[b][w]; nbits a multiple of 32. */
+int qsae_activation_counts_bits(const uint32_t* zbits, int64_t words_ld, int B, int nbits, unsigned long long* counts,
+                                qsae_stream_t stream);
+/* coact[a][c] += 1 for every ordered pair of units active in the same row, diagonal included: the reference's
+ * mask_int.t() @ mask_int (dynamic_analysis.py:296, 411), accumulated over calls into an int32 [H][ld] matrix. */
+int qsae_coactivation_sparse(const int32_t* idx, const float* val, int B, int k, int H, int32_t* coact, int64_t ld,
+                             qsae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

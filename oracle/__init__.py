@@ -293,3 +293,11 @@ def residual_forward(x, stages, *, abs_range: float):
         residual = ((residual - out["reconstruction"]).astype(np.float32) * np.float32(2)).astype(np.float32)
     return {"latent_groups": np.asarray(groups, dtype=np.float32),
             "reconstruction_levels": np.stack(levels), "reconstruction": levels[-1]}
+
+
+# ---- consumers of the sparse latent (scripts/analysis/dynamic_analysis.py:255-311) -------------------------
+def activation_stats(mask: np.ndarray):
+    """(activation_counts int64 [H], coactivation int32 [H, H]) of a boolean activation mask [B, H]:
+    ``mask.sum(dim=0)`` and ``mask_int.t() @ mask_int`` (dynamic_analysis.py:292-296)."""
+    m = np.asarray(mask).astype(np.int32)
+    return m.sum(axis=0).astype(np.int64), (m.T @ m).astype(np.int32)

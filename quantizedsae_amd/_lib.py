@@ -50,6 +50,9 @@ SIGNATURES = {
     "qsae_decode_matryoshka": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_pack_bits_gt": (_i, [_vp, _i64, _i, _i, _f, _vp, _i64, _vp]),
     "qsae_sq_err_sum": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "qsae_activation_counts": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "qsae_activation_counts_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "qsae_coactivation_sparse": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
 }
 
 

@@ -18,7 +18,7 @@ LIBDIR = PKG / "lib"
 LIB = LIBDIR / "libqsae_hip.so"
 OBJDIR = PKG / "lib" / "obj"
 
-SOURCES = ["encode.hip", "topk.hip", "binary.hip", "dense_dec.hip", "encode_topk.hip", "misc.hip"]
+SOURCES = ["encode.hip", "topk.hip", "binary.hip", "dense_dec.hip", "encode_topk.hip", "misc.hip", "analysis.hip"]
 HEADERS = sorted(p.name for p in (Path(__file__).resolve().parent / "csrc").glob("*.h"))   # every header: all sources rebuild
 ARCH = "gfx950"
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",

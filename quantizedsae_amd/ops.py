@@ -386,3 +386,43 @@ def sq_err_sum(recon: torch.Tensor, x: torch.Tensor, acc: Optional[torch.Tensor]
         acc = torch.zeros((), dtype=torch.float64, device=x.device)
     check(_lib.load().qsae_sq_err_sum(_p(recon), _p(x), recon.numel(), _p(acc), _stream()))
     return acc
+
+
+# ---- consumers of the sparse latent (activation statistics) ---------------------------------------------
+def activation_counts(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
+                      counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """counts[h] += #rows whose entry h is active (val > 0; every listed entry when val is None).  int64 [H]."""
+    _dev(idx, "idx", torch.int32)
+    B, k = idx.shape
+    if val is not None:
+        _dev(val, "val", torch.float32)
+    if counts is None:
+        counts = torch.zeros((H,), dtype=torch.int64, device=idx.device)
+    check(_lib.load().qsae_activation_counts(_p(idx.contiguous()), _p(val.contiguous()) if val is not None else None,
+                                             B, k, H, _p(counts), _stream()))
+    return counts
+
+
+def activation_counts_bits(zbits: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """counts[32 w + j] += popcount over rows of bit j of word w.  zbits int32 [B, words]; int64 [32 * words]."""
+    _dev(zbits, "zbits", torch.int32)
+    B, words = zbits.shape
+    if counts is None:
+        counts = torch.zeros((32 * words,), dtype=torch.int64, device=zbits.device)
+    check(_lib.load().qsae_activation_counts_bits(_p(zbits), zbits.stride(0) if B else words, B, 32 * words, _p(counts),
+                                                  _stream()))
+    return counts
+
+
+def coactivation_sparse(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
+                        coact: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """coact[a, c] += #rows in which units a and c are both active (mask^T @ mask).  int32 [H, H]."""
+    _dev(idx, "idx", torch.int32)
+    B, k = idx.shape
+    if val is not None:
+        _dev(val, "val", torch.float32)
+    if coact is None:
+        coact = torch.zeros((H, H), dtype=torch.int32, device=idx.device)
+    check(_lib.load().qsae_coactivation_sparse(_p(idx.contiguous()), _p(val.contiguous()) if val is not None else None,
+                                               B, k, H, _p(coact), coact.stride(0), _stream()))
+    return coact

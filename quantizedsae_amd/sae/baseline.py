@@ -47,11 +47,22 @@ class BaselineSparseAutoencoder(nn.Module):
             return h, recon
 
     def forward_compact(self, x):
+        """(idx, val, reconstruction) without the dense latent; same path selection as forward()."""
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            xp, Wp, kperm = self.encoder.operands(x)
-            idx, val = ops.encode_topk(xp, Wp, lin.bias, self.topk, kperm=kperm)
+            H = lin.weight.shape[0]
+            big = x.shape[0] >= 2048 and H >= 8192
+            if big and self.latent_path in ("auto", "prefilter") and \
+                    ops.prefilter_supported(x.shape[0], lin.weight.shape[1], H, self.topk):
+                pw = self._pref_cache.get((lin.weight, lin.bias), lambda: dict(zip(
+                    ("Wq", "meta"), ops.prefilter_pack_w(lin.weight.detach(), lin.bias.detach()))))
+                xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                idx, val, _ = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
+                                                        self.topk, want_dense=False)
+            else:
+                xp, Wp, kperm = self.encoder.operands(x)
+                idx, val = ops.encode_topk(xp, Wp, lin.bias, self.topk, kperm=kperm)
             return idx, val, ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
 
     def apply_topk_activation(self, h):

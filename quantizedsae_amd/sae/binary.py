@@ -107,12 +107,19 @@ class BinarySAE(SparseAutoencoder):
         return int(self.hidden_dim * self.k)
 
     def forward_compact(self, x):
-        """(idx int32 [B,k], val fp32 [B,k], reconstruction [B,D]) without the dense latent."""
+        """(idx int32 [B,k], val fp32 [B,k], reconstruction [B,D]) without the dense latent; same path
+        selection (and the same bits) as forward()."""
         with torch.no_grad():
             x = require_device_input(x, "x")
             lin = self.encoder.linear
-            xp, Wp, kperm = self.encoder.operands(x)
-            idx, val = ops.encode_topk(xp, Wp, lin.bias, self.top_k, kperm=kperm)
+            if self.resolved_latent_path(x.shape[0]) == "prefilter":
+                pw = self._prefilter_weights()
+                xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                idx, val, _ = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
+                                                        self.top_k, want_dense=False)
+            else:
+                xp, Wp, kperm = self.encoder.operands(x)
+                idx, val = ops.encode_topk(xp, Wp, lin.bias, self.top_k, kperm=kperm)
             return idx, val, self.decoder.decode_sparse(idx, val)
 
     #: "auto" | "fused" | "inplace" | "prefilter".  fused: exact-fp32 encoder+top-k without a dense

@@ -1,0 +1,126 @@
+"""Activation statistics from the compact / bit-packed latent: integer work, bit-exact
+against the oracle's mask arithmetic and against masks the reference itself produced (golden fixtures)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_util import Fixture
+from quantizedsae_amd import BaselineSparseAutoencoder, BinarySAE, QuantizedMatryoshkaSAE, synthetic as S
+from quantizedsae_amd.inference import analysis as A
+from quantizedsae_amd.inference import framework as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _ops():
+    from quantizedsae_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("B,k,H", [(37, 5, 64), (300, 65, 1024), (1, 1, 32), (129, 256, 4096)])
+def test_counts_and_coactivation_from_compact_rows(B, k, H):
+    ops = _ops()
+    rng = np.random.default_rng(B * 7 + k)
+    idx = np.stack([rng.permutation(H)[:k] for _ in range(B)]).astype(np.int32)
+    val = rng.standard_normal((B, k)).astype(np.float32)          # about half the entries are inactive (<= 0)
+    val[0, 0] = 0.0
+    mask = np.zeros((B, H), bool)
+    np.put_along_axis(mask, idx.astype(np.int64), val > 0, axis=1)
+    want_counts, want_co = oracle.activation_stats(mask)
+    counts = ops.activation_counts(dev(idx), dev(val), H)
+    coact = ops.coactivation_sparse(dev(idx), dev(val), H)
+    assert np.array_equal(host(counts), want_counts)
+    assert np.array_equal(host(coact), want_co)
+    # accumulation over calls, and val=None counts every listed entry
+    ops.activation_counts(dev(idx), dev(val), H, counts)
+    assert np.array_equal(host(counts), 2 * want_counts)
+    all_on = np.zeros((B, H), bool)
+    np.put_along_axis(all_on, idx.astype(np.int64), True, axis=1)
+    assert np.array_equal(host(ops.activation_counts(dev(idx), None, H)), all_on.sum(0))
+    assert np.array_equal(host(ops.coactivation_sparse(dev(idx), None, H)), oracle.activation_stats(all_on)[1])
+
+
+@pytest.mark.parametrize("B,words", [(5, 1), (333, 7), (1030, 64)])
+def test_counts_from_packed_bits(B, words):
+    ops = _ops()
+    bits = S.fair_bits(41, (B, 32 * words))
+    packed = np.packbits(bits, axis=1, bitorder="little").view(np.int32)
+    got = host(ops.activation_counts_bits(dev(packed)))
+    assert np.array_equal(got, bits.sum(0).astype(np.int64))
+
+
+def _wrap(name, model):
+    return F.SAEWrapper(F.SAE_REGISTRY[name], model, DEV)
+
+
+def _load(model, sd):
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+    return model.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", ["binary_small", "baseline_small"])
+def test_activation_stats_match_reference_masks(name):
+    """mask / counts / co-activation / tokens per feature against the reference's own sparse latent."""
+    fx = Fixture(name)
+    m, sd = fx.meta, fx.state_dict()
+    if m["variant"] == "binary":
+        model = _load(BinarySAE(m["D"], m["H"], gamma=m["gamma"], n_bits=m["n_bits"]), sd)
+        model.k = m["k"] / m["H"]
+        sae = _wrap("b_sae", model)
+    else:
+        model = _load(BaselineSparseAutoencoder(m["D"], m["H"]), sd)
+        sae = _wrap("baseline_sae", model)
+    x = fx.x()[: fx["sparse_latent"].shape[0]]
+    ref_mask = fx["sparse_latent"] > 0
+    rows_ok = np.ones(len(x), bool)
+    if "gap" in fx:                                        # rows whose k/(k+1) gap is a near-tie may pick another unit
+        from golden_util import NEAR_TIE_EPS
+        rows_ok = fx["gap"][: len(x)] > NEAR_TIE_EPS
+    mask = A._activation_mask(sae, dev(x)).numpy()
+    assert mask.dtype == np.bool_ and np.array_equal(mask[rows_ok], ref_mask[rows_ok])
+    want_counts, want_co = oracle.activation_stats(mask)
+    n = len(x)
+    tpc = 2 if n % 2 == 0 else 1
+    tokens = torch.arange(n, dtype=torch.long).reshape(-1, tpc) * 3 + 1
+    cut = max(1, n // 3)
+    loader = [torch.from_numpy(x[:cut]), [torch.from_numpy(x[cut:])]]        # tensors and (tensor,) batches
+    st = A.compute_activation_stats(sae, loader, token_ids=tokens, tokens_per_context=tpc)
+    assert np.array_equal(st["activation_counts"].numpy(), want_counts)
+    assert np.array_equal(st["coactivation"].numpy(), want_co)
+    flat_tok = tokens.reshape(-1).numpy()
+    for f in range(m["H"]):
+        assert st["tokens_per_feature"][f] == flat_tok[np.nonzero(mask[:, f])[0]].tolist()
+    l0 = A.compute_l0_by_level(sae, loader)
+    assert l0.shape == (1,) and float(l0[0]) == pytest.approx(mask.sum() / len(x), rel=1e-12)
+
+
+def test_matryoshka_mask_and_l0_match_reference_bits():
+    fx = Fixture("matryoshka_small")
+    m, sd = fx.meta, fx.state_dict()
+    model = _load(QuantizedMatryoshkaSAE(m["D"], m["H"], 32, abs_range=m["abs_range"], n_bits=m["n_bits"]), sd)
+    sae = _wrap("q_sae", model)
+    x = fx.x()
+    ref_mask = np.unpackbits(fx["zbits"], axis=1)[:, : m["H"]].astype(bool)
+    mask = A._activation_mask(sae, dev(x)).numpy()
+    assert np.array_equal(mask, ref_mask)
+    l0 = A.compute_l0_by_level(sae, [torch.from_numpy(x)]).numpy()
+    bounds = np.cumsum([0] + list(m["sizes"]))
+    want = np.array([ref_mask[:, bounds[i]:bounds[i + 1]].sum() / len(x) for i in range(len(m["sizes"]))])
+    np.testing.assert_allclose(l0, want, rtol=1e-12)
+    st = A.compute_activation_stats(sae, [torch.from_numpy(x)], token_ids=torch.zeros((len(x), 1), dtype=torch.long),
+                                    tokens_per_context=1, with_tokens=False)
+    want_counts, want_co = oracle.activation_stats(ref_mask)
+    assert np.array_equal(st["activation_counts"].numpy(), want_counts)
+    assert np.array_equal(st["coactivation"].numpy(), want_co)
