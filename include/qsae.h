@@ -207,6 +207,14 @@ int qsae_activation_counts_bits(const uint32_t* zbits, int64_t words_ld, int B, 
 int qsae_coactivation_sparse(const int32_t* idx, const float* val, int B, int k, int H, int32_t* coact, int64_t ld,
                              qsae_stream_t stream);
 
+/* -- activation quantizer of the binary datasets (src/quantized_sae/data/dataset.py:76-102) ----------------- */
+/* bits[b][d*n + j] = bit j (LSB first, as 0.0 / 1.0) of the n-bit code of x[b][d]:
+ *   is_signed = 0 (quantize):        int(round(clamp((x * sf) * 2 + 2^(n-1), 0, 2^n - 1)))
+ *   is_signed = 1 (quantize_signed): int(round(clamp(x * sf, -2^(n-1), 2^(n-1) - 1))) & (2^n - 1)
+ * with sf = scale_factor = 2^(n-1) / (gamma + 1e-5) rounded to fp32, round half to even. */
+int qsae_quantize_bits(const float* x, int64_t ld, int B, int D, int n_bits, float scale_factor, int is_signed,
+                       float* bits, qsae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,3 +301,36 @@ def activation_stats(mask: np.ndarray):
     ``mask.sum(dim=0)`` and ``mask_int.t() @ mask_int`` (dynamic_analysis.py:292-296)."""
     m = np.asarray(mask).astype(np.int32)
     return m.sum(axis=0).astype(np.int64), (m.T @ m).astype(np.int32)
+
+
+# ---- activation quantizer of the binary datasets (src/quantized_sae/data/dataset.py:76-102) ------------------
+def quantize_bits(x: np.ndarray, n_bits: int, scale_factor: float, signed: bool = True) -> np.ndarray:
+    """LSB-first 0/1 floats [B, D * n_bits] of the n-bit activation codes; fp32 arithmetic step by step,
+    round half to even, NaN -> INT_MIN like torch's .int()."""
+    x = np.asarray(x, dtype=np.float32)
+    sf = np.float32(scale_factor)
+    t = (x * sf).astype(np.float32)
+    half = np.float32(2 ** (n_bits - 1))
+    if signed:
+        lo, hi = -half, half - np.float32(1)
+    else:
+        t = (t * np.float32(2)).astype(np.float32)
+        t = (t + half).astype(np.float32)
+        lo, hi = np.float32(0), np.float32(2 ** n_bits - 1)
+    with np.errstate(invalid="ignore"):
+        c = np.where(t < lo, lo, t)
+        c = np.where(c > hi, hi, c)
+        q = np.where(np.isnan(c), np.int64(-2 ** 31), np.rint(c).astype(np.int64))
+    u = (q & (2 ** n_bits - 1)).astype(np.uint32)
+    bits = ((u[..., None] >> np.arange(n_bits, dtype=np.uint32)) & 1).astype(np.float32)
+    return bits.reshape(x.shape[0], -1)
+
+
+# ---- BinaryLatentSAE (sae/binary_latent.py:6-28) -----------------------------------------------------------
+def binary_latent_forward(x, enc_w, enc_b, dec_w, dec_b) -> dict:
+    """binary_latent = (sigmoid(encoder pre-activation) >= 0.5) as 0/1 floats; reconstruction = decoder Linear of
+    the binary latent (the reference feeds latent + (binary - latent), equal to it up to one rounding)."""
+    pre = encode(x, enc_w, enc_b)
+    _gt, ge = sigmoid_cutoffs()
+    binary = (pre >= ge).astype(np.float32)
+    return {"pre": pre, "binary_latent": binary, "reconstruction": encode(binary, dec_w, dec_b)}

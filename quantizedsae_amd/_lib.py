@@ -53,6 +53,7 @@ SIGNATURES = {
     "qsae_activation_counts": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "qsae_activation_counts_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "qsae_coactivation_sparse": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "qsae_quantize_bits": (_i, [_vp, _i64, _i, _i, _i, _f, _i, _vp, _vp]),
 }
 
 

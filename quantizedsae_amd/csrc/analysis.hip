@@ -73,6 +73,41 @@ coactivation_sparse_kernel(const int32_t* __restrict__ idx, const float* __restr
     }
 }
 
+// n-bit activation quantizer of the reference's binary datasets (src/quantized_sae/data/dataset.py:76-102):
+//   unsigned (quantize):        q = int(round(clamp((x * sf) * 2 + 2^(n-1), 0, 2^n - 1)))
+//   signed   (quantize_signed): q = int(round(clamp(x * sf, -2^(n-1), 2^(n-1) - 1))) & (2^n - 1)
+// out[b][d * n + j] = bit j of q (LSB first) as 0.0 / 1.0; every fp32 operation rounded separately, round =
+// half-to-even (torch.round).  One thread per element.
+__global__ void __launch_bounds__(256)
+quantize_bits_kernel(const float* __restrict__ x, int64_t ld, long long total, int D, int n_bits, float sf,
+                     int is_signed, float* __restrict__ out) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / D;
+    const int d = static_cast<int>(i - b * D);
+    const float v = x[b * ld + d];
+    float t = v * sf;
+    const float half_range = static_cast<float>(1 << (n_bits - 1));
+    float lo, hi;
+    if (is_signed) {
+        lo = -half_range;
+        hi = half_range - 1.0f;
+    } else {
+        t = t * 2.0f;
+        t = t + half_range;
+        lo = 0.0f;
+        hi = static_cast<float>((1 << n_bits) - 1);
+    }
+    // torch.clamp: NaN stays NaN (and becomes INT_MIN in .int()); min/max otherwise
+    float c = t;
+    if (c < lo) c = lo;
+    if (c > hi) c = hi;
+    const int q = (c != c) ? static_cast<int>(0x80000000u) : static_cast<int>(rintf(c));
+    const unsigned u = static_cast<unsigned>(q) & ((1u << n_bits) - 1u);
+    float* o = out + i * n_bits;
+    for (int j = 0; j < n_bits; ++j) o[j] = static_cast<float>((u >> j) & 1u);
+}
+
 }  // namespace qsae
 
 using namespace qsae;
@@ -116,6 +151,20 @@ extern "C" int qsae_coactivation_sparse(const int32_t* idx, const float* val, in
     QSAE_CHECK_SUPPORTED(k <= kCoactMaxK, "k <= 256");
     hipLaunchKernelGGL(coactivation_sparse_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), idx, val, B, k,
                        H, coact, ld);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+extern "C" int qsae_quantize_bits(const float* x, int64_t ld, int B, int D, int n_bits, float scale_factor,
+                                  int is_signed, float* bits, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0, "B >= 0, D > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(x && bits, "null pointer");
+    QSAE_CHECK_ARG(ld >= D, "ld < D");
+    QSAE_CHECK_SUPPORTED(n_bits >= 1 && n_bits <= 16, "1 <= n_bits <= 16");
+    const long long total = static_cast<long long>(B) * D;
+    hipLaunchKernelGGL(quantize_bits_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), x, ld, total, D, n_bits, scale_factor, is_signed, bits);
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }

@@ -426,3 +426,13 @@ def coactivation_sparse(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
     check(_lib.load().qsae_coactivation_sparse(_p(idx.contiguous()), _p(val.contiguous()) if val is not None else None,
                                                B, k, H, _p(coact), coact.stride(0), _stream()))
     return coact
+
+
+def quantize_bits(x: torch.Tensor, n_bits: int, scale_factor: float, signed: bool = True) -> torch.Tensor:
+    """n-bit code of every activation as LSB-first 0/1 floats, [B, D * n_bits] (data/dataset.py:76-102)."""
+    x = _f32c(x, "x")
+    B, D = x.shape
+    out = torch.empty((B, D * n_bits), dtype=torch.float32, device=x.device)
+    check(_lib.load().qsae_quantize_bits(_p(x), D, B, D, int(n_bits), float(scale_factor), 1 if signed else 0, _p(out),
+                                         _stream()))
+    return out

@@ -124,3 +124,61 @@ def test_matryoshka_mask_and_l0_match_reference_bits():
     want_counts, want_co = oracle.activation_stats(ref_mask)
     assert np.array_equal(st["activation_counts"].numpy(), want_counts)
     assert np.array_equal(st["coactivation"].numpy(), want_co)
+
+
+# ---- chunk datasets, activation quantizers, BinaryLatentSAE --------------------------------
+def test_quantize_bits_kernel_matches_oracle_and_reference():
+    ops = _ops()
+    fx = Fixture("quantize_bits")
+    x = fx["x"].copy()
+    for n_bits, gamma in fx.meta["configs"]:
+        sf = 2 ** (n_bits - 1) / (gamma + 1e-5)
+        for nm, signed in (("quantize", False), ("quantize_signed", True)):
+            want = np.unpackbits(fx[f"{nm}_n{n_bits}"], axis=1)[:, : x.shape[1] * n_bits].astype(np.float32)
+            got = host(ops.quantize_bits(dev(x), n_bits, sf, signed=signed))
+            assert np.array_equal(got, want), (nm, n_bits)
+    big = S.normal(72, (1000, 512), stream=1, std=3.0).astype(np.float32)
+    big[5, 7] = np.nan
+    big[6, 8] = np.inf
+    for signed in (False, True):
+        assert np.array_equal(host(ops.quantize_bits(dev(big), 4, 2 ** 3 / (4 + 1e-5), signed=signed)),
+                              oracle.quantize_bits(big, 4, 2 ** 3 / (4 + 1e-5), signed=signed))
+
+
+def test_chunk_datasets(tmp_path):
+    from quantizedsae_amd import data as Dd
+    chunk = torch.from_numpy(S.normal(73, (6, 5, 64), stream=1, std=2.0).astype(np.float16))   # [ctx, tok, D] as stored
+    path = tmp_path / "chunk.pt"
+    torch.save(chunk, path)
+    ds = Dd.HiddenStatesTorchDataset(path)
+    assert len(ds) == 30 and ds.files_info[1:] == (6, 5, 64)
+    flat = chunk.reshape(30, 64).float()
+    assert torch.equal(ds[7], flat[7]) and ds[7].dtype == torch.float32
+    # row shards of two ranks tile the chunk; batches arrive on the device as fp32
+    got = [torch.cat(list(ds.iter_batches(4, DEV, world_size=2, rank=r))) for r in (0, 1)]
+    assert torch.equal(torch.cat(got).cpu(), flat)
+    dsb = Dd.HiddenStatesTorchDatasetInBinary(path, gamma=4, n_bits=4)
+    want = oracle.quantize_bits(flat.numpy(), 4, dsb.scale_factor, signed=True)
+    assert np.array_equal(dsb[3].numpy(), want[3])                           # per-sample face: quantize_signed
+    assert np.array_equal(dsb.quantize(flat[3]).numpy(), oracle.quantize_bits(flat[3:4].numpy(), 4, dsb.scale_factor,
+                                                                               signed=False)[0])
+    assert np.array_equal(host(dsb.quantize_batch(flat.to(DEV))), want)      # batch face: one kernel
+    assert torch.equal(dsb.__getoriginalitem__(3), flat[3])
+
+
+def test_binary_latent_sae():
+    from quantizedsae_amd.sae import BinaryLatentSAE
+    fx = Fixture("binary_latent_small")
+    m = fx.meta
+    sd = {k[3:]: a for k, a in fx.arrays.items() if k.startswith("sd.")}
+    model = _load(BinaryLatentSAE(m["D"], m["H"]), sd)
+    binary, recon = model(dev(fx["x"]))
+    want = oracle.binary_latent_forward(fx["x"], sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                        sd["decoder.bias"])
+    assert np.array_equal(host(binary), want["binary_latent"])              # bit-exact vs the oracle
+    assert np.array_equal(host(recon), want["reconstruction"])
+    from golden_util import NEAR_TIE_EPS, row_rel_err
+    rows_ok = fx["pre_min_abs_margin"] > NEAR_TIE_EPS
+    ref_bits = np.unpackbits(fx["binary_latent"], axis=1)[:, : m["H"]].astype(np.float32)
+    assert np.array_equal(host(binary)[rows_ok], ref_bits[rows_ok])         # vs the reference's own output
+    assert row_rel_err(host(recon), fx["reconstruction"])[rows_ok].max() < 1e-5

@@ -176,3 +176,29 @@ def test_torch_restatement_matches_reference(name):
     assert (nz.sum(axis=1) == m["k"]).all()
     got_idx = np.stack([np.nonzero(r)[0] for r in nz]).astype(np.int32)
     assert np.array_equal(got_idx, fx["topk_idx"])
+
+
+# ---- activation quantizers and BinaryLatentSAE ------------------------------------------
+def test_quantize_bits_matches_reference():
+    """oracle.quantize_bits against the reference's HiddenStatesTorchDatasetInBinary.quantize / quantize_signed."""
+    fx = Fixture("quantize_bits")
+    x = fx["x"]
+    for n_bits, gamma in fx.meta["configs"]:
+        sf = 2 ** (n_bits - 1) / (gamma + 1e-5)
+        for nm, signed in (("quantize", False), ("quantize_signed", True)):
+            want = np.unpackbits(fx[f"{nm}_n{n_bits}"], axis=1)[:, : x.shape[1] * n_bits].astype(np.float32)
+            got = oracle.quantize_bits(x, n_bits, sf, signed=signed)
+            assert np.array_equal(got, want), (nm, n_bits)
+
+
+def test_binary_latent_forward_matches_reference():
+    fx = Fixture("binary_latent_small")
+    m = fx.meta
+    sd = {k[3:]: a for k, a in fx.arrays.items() if k.startswith("sd.")}
+    got = oracle.binary_latent_forward(fx["x"], sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                       sd["decoder.bias"])
+    want_bits = np.unpackbits(fx["binary_latent"], axis=1)[:, : m["H"]].astype(np.float32)
+    rows_ok = fx["pre_min_abs_margin"] > NEAR_TIE_EPS          # no pre-activation within 4e-6 of the cutoff
+    assert rows_ok.sum() >= len(rows_ok) - 2
+    assert np.array_equal(got["binary_latent"][rows_ok], want_bits[rows_ok])
+    assert row_rel_err(got["reconstruction"], fx["reconstruction"])[rows_ok].max() < 1e-5

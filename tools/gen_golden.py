@@ -226,7 +226,48 @@ def main():
     main_tail(ref, only)
 
 
+def gen_binary_latent(ref, name, seed, D, H, B):
+    """BinaryLatentSAE (sae/binary_latent.py:6-28): sigmoid encoder, latent >= 0.5, dense decoder."""
+    sd = {"encoder.0.weight": S.xavier_uniform(seed, H, D, stream=1),
+          "encoder.0.bias": S.normal(seed, (H,), stream=2, std=0.05),
+          "decoder.weight": S.uniform(seed, (D, H), -1.0 / np.sqrt(H), 1.0 / np.sqrt(H), stream=3),
+          "decoder.bias": S.normal(seed, (D,), stream=4, std=0.1)}
+    x = S.activations(seed, B, D)
+    model = ref.BinaryLatentSAE(D, H)
+    load_sd(model, sd)
+    with torch.no_grad():
+        binary_latent, recon = model(t(x))
+        pre = torch.nn.functional.linear(t(x), t(sd["encoder.0.weight"]), t(sd["encoder.0.bias"]))
+    save(name, dict(variant="binary_latent", seed=seed, D=D, H=H, B=B),
+         x=x, binary_latent=np.packbits(binary_latent.numpy().astype(np.uint8), axis=1),
+         reconstruction=recon.numpy(), pre_min_abs_margin=np.abs(pre.numpy() + 1.7881390590446244e-07).min(axis=1),
+         **{f"sd.{k}": v for k, v in sd.items()})
+
+
+def gen_quantize_bits(ref):
+    """n-bit activation quantizers of the binary dataset class (data/dataset.py:76-102), called unbound on a stub
+    that carries the attributes the methods read."""
+    import types
+    cls = ref.dataset.HiddenStatesTorchDatasetInBinary
+    x = (S.normal(71, (48, 64), stream=1, std=2.0)).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1e-9, 3.99999, 4.0, -4.0, 100.0, -100.0]
+    out = {}
+    for n_bits, gamma in ((4, 4), (8, 1.5), (2, 4)):
+        stub = types.SimpleNamespace(n_bits=n_bits, gamma=gamma, shift_factor=2 ** (n_bits - 1),
+                                     scale_factor=2 ** (n_bits - 1) / (gamma + 1e-5))
+        for nm in ("quantize", "quantize_signed"):
+            rows = [getattr(cls, nm)(stub, t(r)).numpy() for r in x]
+            out[f"{nm}_n{n_bits}"] = np.packbits(np.stack(rows).astype(np.uint8), axis=1)
+    save("quantize_bits", dict(variant="quantize_bits", configs=[[4, 4], [8, 1.5], [2, 4]]), x=x, **out)
+
+
 def main_tail(ref, only):
+    if not only or "extras" in only:
+        print("binary latent / quantizers")
+        gen_binary_latent(ref, "binary_latent_small", seed=61, D=64, H=1000, B=9)
+        gen_quantize_bits(ref)
+        if only == {"extras"}:
+            return
     print("matryoshka")
     gen_matryoshka(ref, "matryoshka_small", seed=41, D=64, H=1000, B=7, n_bits=4, abs_range=4.0, store_inputs=True)
     gen_matryoshka(ref, "matryoshka_edge", seed=42, D=64, H=512, B=5, n_bits=4, abs_range=1.5, store_inputs=True,

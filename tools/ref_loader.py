@@ -43,6 +43,8 @@ def load_reference():
     qm = _load("SAEs.quantized_matryoshka_SAE", _SAE / "quantized_matryoshka.py")
     rq = _load("SAEs.residual_quantized_matryoshka_SAE", _SAE / "residual_quantized.py")
     ternary = _load("ref_ternary", _SAE / "ternary.py")
+    blatent = _load("ref_binary_latent", _SAE / "binary_latent.py")
+    dataset = _load("ref_dataset", REF_ROOT / "src" / "quantized_sae" / "data" / "dataset.py")
     framework = _load("ref_framework", _INF / "framework.py")
     ns = types.SimpleNamespace(
         SparseAutoencoder=base.SparseAutoencoder,
@@ -54,6 +56,8 @@ def load_reference():
         ResidualQuantizedSAE=rq.ResidualQuantizedSAE,
         TernarySparseAutoencoder=ternary.TernarySparseAutoencoder,
         STEWeights=ternary.STEWeights,
+        BinaryLatentSAE=blatent.BinaryLatentSAE,
+        dataset=dataset,
         framework=framework,
     )
     return ns
