@@ -34,7 +34,8 @@ int densify_rows(const int32_t* idx, const float* val, int B, int k, int H, floa
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
 constexpr int kCandCap = 1024;     // candidate slots per row
-constexpr int kPilotRank = 20;     // tau = kPilotRank-th largest pilot value
+static int kPilotRank = 20;        // tau = kPilotRank-th largest pilot value (debug-tunable together with the pilot width)
+static int g_pilot_div = 16;       // pilot block = H / g_pilot_div hidden units
 constexpr int kFusedMinRows = 2048;
 constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
@@ -65,7 +66,7 @@ static bool use_fused(int B, int D, int H, int k) {
 }
 
 static int pilot_width(int H) {
-    int p = H / 16;
+    int p = H / g_pilot_div;
     p = (p + 127) / 128 * 128;
     return p;
 }
@@ -989,6 +990,12 @@ extern "C" int qsae_debug_set_refine_stamps(void* buf) {
 
 extern "C" int qsae_debug_set_refine_ablate(int v) {
     g_ref_ablate = v;
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_set_pilot(int div, int rank) {
+    g_pilot_div = div;
+    kPilotRank = rank;
     return QSAE_OK;
 }
 

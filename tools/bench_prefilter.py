@@ -23,6 +23,10 @@ lib = _lib.load()
 lib.qsae_debug_set_prefilter_tile.argtypes = [C.c_int]
 lib.qsae_debug_set_xstat_rot.argtypes = [C.c_int]
 lib.qsae_debug_set_refine_ablate.argtypes = [C.c_int]
+lib.qsae_debug_set_pilot.argtypes = [C.c_int, C.c_int]
+import os
+if os.environ.get('QSAE_PILOT'):
+    lib.qsae_debug_set_pilot(*[int(v) for v in os.environ['QSAE_PILOT'].split(',')])
 
 VARIANTS = [(True, 2, 2), (False, 2, 2), (False, 2, 0), (False, 2, 1), (False, 2, 5), (False, 2, 8), (False, 2, 17),
             (False, 11, 2), (False, 11, 0), (False, 0, 0)]
