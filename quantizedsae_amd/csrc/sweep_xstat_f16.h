@@ -117,17 +117,20 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const int cap_part = a.cap / a.parts;
     int* my_cnt = part == 0 ? a.cnt : a.cnt_parts + static_cast<size_t>(part - 1) * a.B;
     int ld = s_begin;                                        // next stage to issue (absolute stage index)
-    auto issue = [&]() {
+    // One 1-KiB piece of stage `ld` per call (i is a compile-time constant at every call site); wave 0 adds the
+    // stage's bias (kXsHT floats, lanes 0..kXsHT/4-1, 16 bytes each) to piece 0.  Three bias copies in rotation:
+    // while stage s+1 lands, the filter still reads copy s and copy s-1.
+    auto issue_piece = [&](int i) {
         char* dst = xs_smem + (ld % kXsStages) * STAGE_BYTES;
         const char* sb = reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(ld) * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < IPW; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(sb + voff[i]), (lptr_t)(dst + piece[i] * 1024), 16, 0, 0);
-        // the stage's bias (kXsHT floats), by wave 0: lanes 0..kXsHT/4-1, 16 bytes each.  Three copies in
-        // rotation: while stage s+1 lands, waves 0..3 still read copy s and waves 4..7 copy s-1.
-        if (a.bias && wave == 0 && lane < kXsHT / 4)
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb + voff[i]), (lptr_t)(dst + piece[i] * 1024), 16, 0, 0);
+        if (i == 0 && a.bias && wave == 0 && lane < kXsHT / 4)
             __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + static_cast<int64_t>(ld) * kXsHT + 4 * lane),
                                              (lptr_t)(bias_lds + (ld % 3) * BIAS_BYTES), 16, 0, 0);
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) issue_piece(i);
         ++ld;
     };
     if (ld < nstages) issue();
@@ -173,9 +176,11 @@ sweep_xstat_f16_kernel(XsArgs a) {
     auto flush = [&]() {
         if (__builtin_amdgcn_ballot_w64(nrec > 0) != 0ull) {
             asm volatile("" ::: "memory");
-            const int n_other = __shfl_xor(nrec, 32, 64);
+            // partner lane's count: v_permlane32_swap exchanges the half-waves in one VALU instruction
+            const auto sw = __builtin_amdgcn_permlane32_swap(nrec, nrec, false, false);
+            const int n_other = lane_half ? static_cast<int>(sw[0]) : static_cast<int>(sw[1]);
             int pos = count + (lane_half ? (n_other < kXsSlots ? n_other : kXsSlots) : 0);
-            const int mine = nrec < kXsSlots ? nrec : kXsSlots;
+            const int mine = (nrec < kXsSlots ? nrec : kXsSlots) * ((row_ok && ABL != 3) ? 1 : 0);
             // record slots by hand-written ds_reads: in front of a compiler-generated LDS read the compiler
             // drains the vector-memory queue (it cannot know the slots never alias an LDS-DMA in flight),
             // which here would wait for the acknowledgement of the previous stage's fill stores
@@ -191,16 +196,25 @@ sweep_xstat_f16_kernel(XsArgs a) {
                          : "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5])
                          : "v"(ring_addr)
                          : "memory");
-            uint2 rec[kXsSlots];
-#pragma unroll
-            for (int j = 0; j < kXsSlots; ++j)
-                rec[j] = make_uint2(static_cast<unsigned>(rr[j]), static_cast<unsigned>(rr[j] >> 32));
-#pragma unroll
-            for (int j = 0; j < kXsSlots; ++j) {
-                if (j < mine && row_ok && ABL != 3 && pos + j < cap_part)
-                    list[pos + j] = make_uint2(rec[j].x, rec[j].y & 0x07FFFFFFu);
+            // slot j holds a record only for lanes with more than j of them: stop at the first empty level
+            // (typically two or three)
+            auto put = [&](int j) {
+                if (j < mine && pos + j < cap_part)
+                    list[pos + j] = make_uint2(static_cast<unsigned>(rr[j]), static_cast<unsigned>(rr[j] >> 32) & 0x07FFFFFFu);
+            };
+            put(0);
+            if (__builtin_amdgcn_ballot_w64(mine > 1) != 0ull) {
+                put(1);
+                if (__builtin_amdgcn_ballot_w64(mine > 2) != 0ull) {
+                    put(2);
+                    if (__builtin_amdgcn_ballot_w64(mine > 3) != 0ull) {
+                        put(3);
+                        put(4);
+                        put(5);
+                    }
+                }
             }
-            count += mine + (n_other < kXsSlots ? n_other : kXsSlots);
+            count += (nrec < kXsSlots ? nrec : kXsSlots) + (n_other < kXsSlots ? n_other : kXsSlots);
             if (nrec > kXsSlots || n_other > kXsSlots) count = cap_part + 1;  // lost records: exact fallback
             asm volatile("" ::: "memory");
             nrec = 0;
@@ -324,7 +338,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
     constexpr bool FILTER = ABL != 2 && ABL != 8;
     constexpr int VPG = 32 / KB;                             // filter values per pair of MFMAs (KB = 32: 1)
     static_assert(VPG >= 1 && VPG * (KB / 2) == 16, "16 values spread over KB/2 MFMA pairs");
-    auto tile_pass = [&](const char* sbase, int mt, bool do_filter, int fmt, int fst) {
+    // phase 0 (first pass of a stage): one DMA piece of the next stage per MFMA group -- an LDS-DMA issue costs
+    // 60-180 cycles, eight of them at the top of a stage were 5-10 % of it; phase 1: the stage's fill stores, which
+    // must stay younger than every DMA piece for the counted wait at the end of the stage.
+    auto tile_pass = [&](const char* sbase, int mt, bool do_filter, int fmt, int fst, int phase, bool dma) {
         // MFMAs of row tile mt over all of K; in their shadows the filter of acc[fmt] (stage fst)
         auto rd = [&](int kb) {
             return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
@@ -346,7 +363,12 @@ sweep_xstat_f16_kernel(XsArgs a) {
 #pragma unroll
                 for (int u = 0; u < VPG; ++u) filter_value(fmt, (kb / 2) * VPG + u, tag, bq[((kb / 2) * VPG + u) >> 2]);
             }
-            fill_one();
+            if (phase == 0) {
+                if (dma && kb / 4 < IPW) issue_piece(kb / 4);
+            } else {
+                fill_one();
+                fill_one();
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (kb + 4 < KB) { w0 = rd(kb + 4); w1 = rd(kb + 5); }
             __builtin_amdgcn_sched_barrier(0);
@@ -365,16 +387,17 @@ sweep_xstat_f16_kernel(XsArgs a) {
     for (int s = s_begin; s < nstages; ++s) {
         flush();                                             // older than the DMA issued next
         stamp(0);
-        if (ld < nstages) issue();                           // stage s+1 -> the buffer read during stage s-1
+        const bool dma = ld < nstages;                       // stage s+1 -> the buffer read during stage s-1
         fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
-        tile_pass(sbase, 0, s > s_begin, 1, s - 1);
+        tile_pass(sbase, 0, s > s_begin, 1, s - 1, 0, dma);
+        if (dma) ++ld;
         // a lane that already holds four records could overflow its six slots in the second pass: flush now
         // (rare; the stores are younger than the stage's DMA, which only makes the wait below stricter)
         if (__builtin_amdgcn_ballot_w64(nrec > kXsSlots - 3) != 0ull) flush();
         stamp(2);
-        tile_pass(sbase, 1, true, 0, s);
+        tile_pass(sbase, 1, true, 0, s, 1, false);
         stamp(3);
         while (fill_left > 0) fill_one();                    // (budgets beyond the 16 slots of a stage)
         // retire stage s+1 (for every wave) before anyone reads it; also frees this stage's buffer
