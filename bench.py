@@ -103,6 +103,54 @@ def cpu_baseline(model, x_sample, max_threads):
                       f"(best at {threads}), host CPU: {cpu_name}"}
 
 
+def secondary_configs(device, x):
+    """forward() wall time of the other configurations of BASELINE.json (3: ternary, 4: matryoshka; plus the
+    baseline top-32 SAE, the residual SAE at half batch, and the compact-output BinarySAE path), same batch,
+    synthetic parameters of SURVEY.md 8d.  Reported beside the headline, never part of `value`."""
+    from quantizedsae_amd import (BaselineSparseAutoencoder, BinarySAE, QuantizedMatryoshkaSAE, ResidualQuantizedSAE,
+                                  TernarySparseAutoencoder)
+    out = []
+
+    def run(name, model, call, rows, flops_per_row):
+        model = model.to(device).eval()
+        xb = x[:rows]
+        with torch.no_grad():
+            for _ in range(2):
+                r = call(model, xb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                r = call(model, xb)
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        del r, model
+        torch.cuda.empty_cache()
+        out.append({"config": name, "rows": rows, "ms_per_step": ms, "activations_per_s": rows / ms * 1e3,
+                    "algorithmic_tflops": flops_per_row * rows / ms / 1e9})
+
+    B = x.shape[0]
+    with torch.no_grad():
+        m = TernarySparseAutoencoder(D, H)
+        m.decoder.weight.normal_(0, 0.5)
+        run("config 3: TernarySparseAutoencoder(512,32768), dense latent + reconstruction", m, lambda mm, xx: mm(xx), B,
+            4.0 * D * H)
+        m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)
+        m.encoder[0].bias.fill_(-0.44)
+        m.decoder.weight.uniform_(-1, 1)
+        m.decoder.weight_mirror.uniform_(-1, 1)
+        run("config 4: QuantizedMatryoshkaSAE(512,32768,n_bits=4), 4 reconstruction levels", m, lambda mm, xx: mm(xx), B,
+            4.0 * D * H)
+        run("baseline_sae: BaselineSparseAutoencoder(512,32768) top-32", BaselineSparseAutoencoder(D, H),
+            lambda mm, xx: mm(xx), B, 2.0 * D * H + 2.0 * 32 * D)
+        m = ResidualQuantizedSAE(D, H, top_k=32, abs_range=1.5, n_bits=4)
+        run("rq_sae: ResidualQuantizedSAE(512,32768,n_bits=4)", m, lambda mm, xx: mm(xx), min(B, 32768), 4.0 * D * H)
+        m = BinarySAE(D, H, gamma=GAMMA, n_bits=N_BITS)
+        m.decoder.weight.copy_(torch.where(torch.rand_like(m.decoder.weight) > 0.5, 30.0, -30.0))
+        run("config 2, compact outputs (idx, val, reconstruction; no dense latent)", m,
+            lambda mm, xx: mm.forward_compact(xx), B, 2.0 * D * H + 2.0 * K_TOP * D)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +161,7 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=4096)
     ap.add_argument("--latent-path", default="auto", choices=["auto", "fused", "inplace", "prefilter"])
     ap.add_argument("--no-fp32-reference", action="store_true", help="skip the extra fp32-only measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (rank 0, N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,6 +308,8 @@ def main():
             out["roofline"].update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                     "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": algo_bytes,
                                     "also": mfma_view})
+        if world == 1 and not args.no_secondary:
+            out["secondary_configs"] = secondary_configs(device, x)
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             try:
