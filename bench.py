@@ -248,8 +248,8 @@ def main():
             enc_ms, peak = sweep_ms, PEAK_FP16_MFMA_TFLOPS
             achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
             kname = (f"sweep_xstat_f16_kernel<32> (fp16 MFMA candidate sweep {B}x512 @ 512x{int(round(H * sweep_frac))}: "
-                     "activation panel stationary in registers, weights streamed once per workgroup, threshold filter in "
-                     "the MFMA shadows, plus the zero-fill of the dense [B,32768] latent)")
+                     "activation panel stationary in registers, weights streamed once per workgroup, in-kernel pilot pass and "
+                     "threshold, threshold filter in the MFMA shadows, plus the zero-fill of the dense [B,32768] latent)")
             tkey = "sweep_xstat_f16"
         elif sweep_n:
             enc_ms, peak = sweep_ms, PEAK_FP32_MFMA_TFLOPS

@@ -41,6 +41,8 @@ constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
+static int g_inkernel_pilot = 1;   // the stationary sweep derives tau itself (no pilot GEMM / selection launches)
+static int g_inkernel_rank = 14;   // tau = this rank among the row's 32 group maxima
 static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
 static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
@@ -860,15 +862,21 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     // zero-fill their own blocks in the epilogue instead and the survivors are scattered in afterwards.
     const bool xstat = g_pref_tile == 2 && xstat_supported(D, H - P, P) && H % 4 == 0;
     float* fused_fill = xstat ? nullptr : dense;
-    // activation-stationary sweep: it also zero-fills the dense latent (all H columns, spread over its stages)
-    const int xs_stages = (H - P) / kXsHT;
-    const int fill_cw = xs_stages > 0 ? (32 * (H / 256) + xs_stages - 1) / xs_stages : 0;   // 1-KiB pieces per wave and stage
-    const bool fill_in_sweep = xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
+    // In-kernel pilot: the stationary sweep derives tau itself from the first P hidden units (group maxima, see
+    // sweep_xstat_f16.h) and then sweeps ALL hidden units; no pilot GEMM, no pilot buffer, no seeds.
+    const bool inkernel = xstat && g_inkernel_pilot && P % kXsHT == 0 && H % kXsHT == 0 && xstat_supported(D, H, 0);
+    const int Hs = inkernel ? H : H - P;                     // hidden units the sweep launch covers
+    const int hoff = inkernel ? 0 : P;
     // small batches: the hidden range of the sweep is split over `parts` workgroup columns, each with its own
     // segment of every row's candidate list
-    const int parts = xstat ? xstat_parts(B, H - P, kCandCap) : 1;
+    const int parts = xstat ? xstat_parts(B, Hs, kCandCap) : 1;
     const int cap_part = kCandCap / parts;
     int* cnt_parts = reinterpret_cast<int*>(ws + PL.cnt_parts);
+    // activation-stationary sweep: it also zero-fills the dense latent (all H columns, spread over the iterations
+    // of every part: its share of the sweep stages plus the pilot iterations)
+    const int xs_iters = xstat ? (Hs / kXsHT) / parts + (inkernel ? P / kXsHT : 0) : 0;
+    const int fill_cw = xs_iters > 0 ? (32 * (H / 256) / parts + xs_iters - 1) / xs_iters : 0;   // 1-KiB pieces per wave and iteration
+    const bool fill_in_sweep = xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
     // 1. fp16 copy of the batch + per-row scale and error margin
     hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
     QSAE_LAUNCH_CHECK();
@@ -876,8 +884,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     const float* xq_w = reinterpret_cast<const float*>(xq);
     const float* wq_w = reinterpret_cast<const float*>(Wq);
     // 2. approximate pilot block [B][P] (activation rows on registers, hidden units on lanes)
-    {
-        int rc;
+    int rc = QSAE_OK;
+    if (!inkernel) {
         if (g_pilot_tile == 0 && P % 256 == 0) {
             using EpiP = EpiApproxDense<256, 256, 4, 2>;
             typename EpiP::Args ep{inv, bias, pilot, P};
@@ -891,7 +899,7 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     }
     // 3. tau~ = j-th largest approximate pilot value; seeds = pilot elements >= tau~ - 2 eps
     const int j = kPilotRank < P ? kPilotRank : P;
-    int rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, cap_part, fused_fill, dense_ld, s,
+    if (!inkernel) rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, cap_part, fused_fill, dense_ld, s,
                                 margin, kCandCap);
     if (rc != QSAE_OK) return rc;
     // 4. fp16 sweep of the remaining hidden units with the threshold filter (tau~ - 2 eps)
@@ -905,8 +913,9 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
             QSAE_HIP(hipEventRecord(e0, s));
         }
         if (xstat) {
-            XsArgs xa{xq + 0, Wq + static_cast<size_t>(P) * D, bias ? bias + P : nullptr, tau, margin, inv, cand, cnt,
-                      B, H - P, kCandCap, P, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H, fill_cw, parts, cnt_parts};
+            XsArgs xa{xq + 0, Wq + static_cast<size_t>(hoff) * D, bias ? bias + hoff : nullptr, tau, margin, inv, cand, cnt,
+                      B, Hs, kCandCap, hoff, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H,
+                      fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank, tau, parts, cnt_parts};
             rc = launch_xstat(D, xa, s, g_xstat_ablate);
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
@@ -975,6 +984,9 @@ extern "C" int qsae_debug_sweep_timing_collect(double* total_ms, int* launches) 
 
 // fraction of the encoder FLOPs the sweep launch covers (the pilot block takes the rest)
 extern "C" double qsae_debug_sweep_flop_fraction(int H) {
+    // with the in-kernel pilot the sweep launch computes every hidden unit (the pilot block twice; only the
+    // algorithmic 2 B D H are counted)
+    if (g_inkernel_pilot && g_pref_tile == 2 && H % kXsHT == 0 && pilot_width(H) % kXsHT == 0) return 1.0;
     return static_cast<double>(H - pilot_width(H)) / static_cast<double>(H);
 }
 
@@ -996,6 +1008,13 @@ extern "C" int qsae_debug_set_refine_ablate(int v) {
 extern "C" int qsae_debug_set_pilot(int div, int rank) {
     g_pilot_div = div;
     kPilotRank = rank;
+    return QSAE_OK;
+}
+
+// in-kernel pilot of the stationary sweep: enable (0 = separate pilot GEMM + selection), rank among 32 group maxima
+extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
+    g_inkernel_pilot = enable;
+    if (rank > 0) g_inkernel_rank = rank;
     return QSAE_OK;
 }
 

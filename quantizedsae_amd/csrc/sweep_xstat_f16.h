@@ -48,6 +48,9 @@ struct XsArgs {
     long long dense_ld;
     int H;                   // columns of the dense latent (all of them are filled, not only the swept ones)
     int fill_cw;             // 1-KiB pieces (256 columns of one row) a wave fills per stage
+    int pilot_stages;        // > 0: the kernel derives tau itself from the first pilot_stages * 64 hidden units (see below)
+    int pilot_rank;          //   tau = pilot_rank-th largest of the row's 32 group maxima
+    float* tau_out;          //   [B] tau, for the refine step's validity check
     int parts;               // hidden-range split (gridDim.y): part p sweeps stages [p*n/parts, (p+1)*n/parts),
     int* cnt_parts;          //   appends to the row's list segment [p*cap/parts, ...) and counts in cnt_parts[(p-1)*B + row]
 };
@@ -77,7 +80,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const bool row_ok = row < a.B;
     const int crow = row_ok ? row : a.B - 1;
 
-    const float thr = a.tau[crow] - a.margin[crow];
+    const float margin_row = a.margin[crow];
+    const float thr = a.pilot_stages > 0 ? 0.0f : a.tau[crow] - margin_row;      // in-kernel pilot: set after the pilot pass
     const float inv = a.inv[crow];
 
     // ---- stationary operand: this lane's 8 halves of every k-block of its activation row -----------
@@ -116,24 +120,43 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const int nstages = static_cast<int>(static_cast<long long>(part + 1) * all_stages / a.parts);   // end (absolute)
     const int cap_part = a.cap / a.parts;
     int* my_cnt = part == 0 ? a.cnt : a.cnt_parts + static_cast<size_t>(part - 1) * a.B;
-    int ld = s_begin;                                        // next stage to issue (absolute stage index)
-    // One 1-KiB piece of stage `ld` per call (i is a compile-time constant at every call site); wave 0 adds the
-    // stage's bias (kXsHT floats, lanes 0..kXsHT/4-1, 16 bytes each) to piece 0.  Three bias copies in rotation:
-    // while stage s+1 lands, the filter still reads copy s and copy s-1.
+    // Iterations and blocks.  A part runs pilot_stages pilot iterations over hidden blocks 0.. (64 hidden units
+    // each), then its share [s_begin, nstages) of all blocks; iteration `it` uses LDS buffer it % 2 and bias copy
+    // it % 3, block(it) gives the hidden block it works on.
+    const int ps = a.pilot_stages;
+    const int n_iter = ps + (nstages - s_begin);
+    auto block_of = [&](int it) { return it < ps ? it : s_begin + (it - ps); };
+    int ld = 0;                                              // next iteration to issue
+    // One 1-KiB piece of iteration `ld` per call (i is a compile-time constant at every call site); wave 0 adds the
+    // block's bias (kXsHT floats, lanes 0..kXsHT/4-1, 16 bytes each) to piece 0.  Three bias copies in rotation:
+    // while iteration it+1 lands, the filter still reads copy it and copy it-1.
     auto issue_piece = [&](int i) {
+        const int blk = block_of(ld);
         char* dst = xs_smem + (ld % kXsStages) * STAGE_BYTES;
-        const char* sb = reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(ld) * STAGE_BYTES;
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb + voff[i]), (lptr_t)(dst + piece[i] * 1024), 16, 0, 0);
-        if (i == 0 && a.bias && wave == 0 && lane < kXsHT / 4)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + static_cast<int64_t>(ld) * kXsHT + 4 * lane),
+        // block base as an opaque scalar pair: SGPR base + 32-bit lane offset addressing (otherwise the compiler
+        // hoists `wq + voff[i]` as eight 64-bit VGPR pairs out of the loops and spills them)
+        auto scalar_ptr = [](const void* p) {
+            const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+            const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u));
+            const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
+            return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+        };
+        const char* sb = scalar_ptr(reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(blk) * STAGE_BYTES);
+        unsigned vo = voff[i];
+        asm volatile("" : "+v"(vo));                        // keep the offsets 32-bit (no hoisted zero-extended pairs)
+        __builtin_amdgcn_global_load_lds((gptr_t)(sb + vo), (lptr_t)(dst + piece[i] * 1024), 16, 0, 0);
+        if (i == 0 && a.bias && wave == 0 && lane < kXsHT / 4) {
+            const char* bb = scalar_ptr(a.bias + static_cast<int64_t>(blk) * kXsHT);
+            __builtin_amdgcn_global_load_lds((gptr_t)(bb + static_cast<unsigned>(16 * lane)),
                                              (lptr_t)(bias_lds + (ld % 3) * BIAS_BYTES), 16, 0, 0);
+        }
     };
     auto issue = [&]() {
 #pragma unroll
         for (int i = 0; i < IPW; ++i) issue_piece(i);
         ++ld;
     };
-    if (ld < nstages) issue();
+    if (ld < n_iter) issue();
     // Make the compiler retire its own loads (x fragments, threshold, scale) HERE: it cannot see the asm
     // waits below, and a load still pending in its model at the loop header costs a vmcnt(0) per stage.
     float thr_r = thr, inv_r = inv;
@@ -169,7 +192,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // other overflowing row.
     f32x16 acc[MT];
     int nrec = 0;                                            // records in this lane's slots
-    int count = (row_ok && part == 0) ? a.cnt[crow] : 0;     // this part's segment length (equal in both lanes)
+    int count = (row_ok && part == 0 && ps == 0) ? a.cnt[crow] : 0;   // this part's segment length (equal in both lanes)
     uint2* list = a.cand + static_cast<int64_t>(crow) * a.cap + part * cap_part;
     typedef __attribute__((address_space(3))) char* lds_char_t;
     const unsigned ring_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char_t)my_ring));   // LDS byte address
@@ -239,12 +262,12 @@ sweep_xstat_f16_kernel(XsArgs a) {
                      : "vcc", "memory");
     };
     // hidden index of accumulator register 0 of row tile 0 for this lane in stage st, tagged with its row
-    auto stage_tag = [&](int st) {
-        return static_cast<unsigned>(st * kXsHT + a.hidden_offset + 4 * lane_half) |
+    auto stage_tag = [&](int blk) {
+        return static_cast<unsigned>(blk * kXsHT + a.hidden_offset + 4 * lane_half) |
                (static_cast<unsigned>(lane_col) << 27);
     };
-    auto load_bias = [&](int st, int mt, f32x4 (&bq)[4]) {
-        const char* bb = bias_lds + (st % 3) * BIAS_BYTES + 16 * lane_half + mt * 128;
+    auto load_bias = [&](int it, int mt, f32x4 (&bq)[4]) {
+        const char* bb = bias_lds + (it % 3) * BIAS_BYTES + 16 * lane_half + mt * 128;
 #pragma unroll
         for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(bb + 32 * g);
     };
@@ -341,14 +364,32 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // phase 0 (first pass of a stage): one DMA piece of the next stage per MFMA group -- an LDS-DMA issue costs
     // 60-180 cycles, eight of them at the top of a stage were 5-10 % of it; phase 1: the stage's fill stores, which
     // must stay younger than every DMA piece for the counted wait at the end of the stage.
-    auto tile_pass = [&](const char* sbase, int mt, bool do_filter, int fmt, int fst, int phase, bool dma) {
-        // MFMAs of row tile mt over all of K; in their shadows the filter of acc[fmt] (stage fst)
+    // Pilot pass (in-kernel threshold): over the first pilot_stages blocks every lane keeps, per accumulator
+    // register position, the running maximum of its approximate latents -- 16 group maxima per lane, 32 per
+    // row, each over 64 * pilot_stages / 32 hidden units.  tau = the pilot_rank-th largest of the row's 32
+    // maxima: at least pilot_rank pilot values reach it, and it sits at about the same quantile as the 20th
+    // largest of the whole pilot block (1 - F^64 = 14/32 -> 0.9 % tail, ~300 values per row above it).  It
+    // replaces a separate pilot GEMM + per-row selection (0.53 ms) by pilot_stages extra iterations here.
+    float gmax[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gmax[q] = -__builtin_huge_valf();
+    auto track_value = [&](int mt, int q, const f32x4& bq) {
+        const float v = fmaf(acc[mt][q], inv_r, bq[q & 3]);
+        gmax[q] = fmaxf(gmax[q], v);                         // v_max_f32: a NaN operand is ignored
+    };
+    // with_filter: in the MFMA shadows, filter acc[fmt] (block fblk, bias copy of iteration fit)
+    auto tile_pass = [&](const char* sbase, int mt, bool with_filter, int fmt, int fblk, int fit, int phase,
+                         bool dma) __attribute__((always_inline)) {
+        // MFMAs of row tile mt over all of K; in their shadows the epilogue of acc[fmt]
         auto rd = [&](int kb) {
             return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
         };
         f32x4 bq[4];
-        const unsigned tag = stage_tag(fst);
-        if (FILTER && do_filter) load_bias(fst, fmt, bq);
+        const unsigned tag = stage_tag(fblk);
+        if (FILTER && with_filter) load_bias(fit, fmt, bq);
+        auto epilogue = [&](int qv) {
+            if (FILTER && with_filter) filter_value(fmt, qv, tag, bq[qv >> 2]);
+        };
         f16x8 w0 = rd(0), w1 = rd(1), w2, w3;
         f32x16 c;
 #pragma unroll
@@ -359,10 +400,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, xf[kb], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, xf[kb + 1], c, 0, 0, 0);
-            if (FILTER && do_filter) {
 #pragma unroll
-                for (int u = 0; u < VPG; ++u) filter_value(fmt, (kb / 2) * VPG + u, tag, bq[((kb / 2) * VPG + u) >> 2]);
-            }
+            for (int u = 0; u < VPG; ++u) epilogue((kb / 2) * VPG + u);
             if (phase == 0) {
                 if (dma && kb / 4 < IPW) issue_piece(kb / 4);
             } else {
@@ -374,39 +413,91 @@ sweep_xstat_f16_kernel(XsArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, xf[kb + 2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3, xf[kb + 3], c, 0, 0, 0);
-            if (FILTER && do_filter) {
 #pragma unroll
-                for (int u = 0; u < VPG; ++u)
-                    filter_value(fmt, (kb / 2 + 1) * VPG + u, tag, bq[((kb / 2 + 1) * VPG + u) >> 2]);
-            }
+            for (int u = 0; u < VPG; ++u) epilogue((kb / 2 + 1) * VPG + u);
             __builtin_amdgcn_sched_barrier(0);
         }
         acc[mt] = c;
     };
-#pragma unroll 1
-    for (int s = s_begin; s < nstages; ++s) {
+    // tau from the group maxima: MSB-first bisection on the monotone keys of the lane pair's 32 values
+    auto select_tau = [&]() {
+        uint32_t key[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) key[q] = mono_key(gmax[q]);
+        uint32_t T = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = T | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c += key[q] >= trial ? 1 : 0;
+            const auto sw = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+            c += lane_half ? static_cast<int>(sw[0]) : static_cast<int>(sw[1]);
+            if (c >= a.pilot_rank) T = trial;
+        }
+        // key -> value (inverse of mono_key; the maxima are never NaN)
+        return __uint_as_float((T & 0x80000000u) ? (T & 0x7FFFFFFFu) : ~T);
+    };
+    // One iteration = one 64-unit hidden block: flush, (DMA of the next block + MFMAs of row tile 0 + epilogue
+    // of the previous tile 1), (fill stores + MFMAs of row tile 1 + epilogue of tile 0), counted wait, barrier.
+    // Written once, instantiated for the pilot loop and the sweep loop (two loops, so that the pilot's maxima
+    // do not occupy registers during the sweep).
+    auto iteration = [&](int it, bool first) __attribute__((always_inline)) {
+        const int blk = block_of(it);
         flush();                                             // older than the DMA issued next
         stamp(0);
-        const bool dma = ld < nstages;                       // stage s+1 -> the buffer read during stage s-1
+        const bool dma = ld < n_iter;                        // iteration it+1 -> the buffer read during it-1
         fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
         stamp(1);
-        const char* sbase = xs_smem + (s % kXsStages) * STAGE_BYTES;
-        tile_pass(sbase, 0, s > s_begin, 1, s - 1, 0, dma);
+        const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
+        // first pass: epilogue of the previous iteration's row tile 1 (none at the first pilot / first sweep iteration)
+        tile_pass(sbase, 0, !first, 1, block_of(it > 0 ? it - 1 : 0), it - 1, 0, dma);
         if (dma) ++ld;
         // a lane that already holds four records could overflow its six slots in the second pass: flush now
         // (rare; the stores are younger than the stage's DMA, which only makes the wait below stricter)
         if (__builtin_amdgcn_ballot_w64(nrec > kXsSlots - 3) != 0ull) flush();
         stamp(2);
-        tile_pass(sbase, 1, true, 0, s, 1, false);
+        tile_pass(sbase, 1, true, 0, blk, it, 1, false);
         stamp(3);
         while (fill_left > 0) fill_one();                    // (budgets beyond the 16 slots of a stage)
-        // retire stage s+1 (for every wave) before anyone reads it; also frees this stage's buffer
+        // retire iteration it+1 (for every wave) before anyone reads it; also frees this iteration's buffer
         wait_all_but(nfill);
         stamp(4);
         __builtin_amdgcn_s_barrier();
         stamp(5);
+    };
+    if (ps > 0) {
+        // pilot iterations: MFMAs of a row tile, then its maxima right away (64 VALU instructions per iteration,
+        // not worth hiding; deferring them as the sweep does would keep 16 more registers live)
+#pragma unroll 1
+        for (int it = 0; it < ps; ++it) {
+            const bool dma = ld < n_iter;
+            fill_begin_stage();
+            const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                tile_pass(sbase, mt, false, 0, 0, 0, mt, mt == 0 && dma);
+                if (mt == 0 && dma) ++ld;
+                if (FILTER) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + (it % 3) * BIAS_BYTES + 16 * lane_half +
+                                                                         mt * 128 + 32 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) track_value(mt, 4 * g + i, bq);
+                    }
+                }
+            }
+            while (fill_left > 0) fill_one();
+            wait_all_but(nfill);
+            __builtin_amdgcn_s_barrier();
+        }
+        const float tau_row = select_tau();
+        thr_r = tau_row - margin_row;
+        if (part == 0 && row_ok && lane_half == 0) a.tau_out[row] = tau_row;
     }
-    while (a.dense && fill_next < fill_total) {              // (quota * stages covers the block; safety net)
+#pragma unroll 1
+    for (int it = ps; it < n_iter; ++it) iteration(it, it == ps);
+    while (a.dense && fill_next < fill_total) {              // (quota * iterations covers the block; safety net)
         fill_begin_stage();
         while (fill_left > 0) fill_one();
     }
@@ -415,10 +506,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * kXsWaves + wave) * 8 + i] = tacc[i];
     }
-    if (FILTER && nstages > s_begin) {
+    if (FILTER && n_iter > ps) {
         f32x4 bq[4];
-        load_bias(nstages - 1, 1, bq);
-        const unsigned tag = stage_tag(nstages - 1);
+        load_bias(n_iter - 1, 1, bq);
+        const unsigned tag = stage_tag(block_of(n_iter - 1));
 #pragma unroll
         for (int q = 0; q < 16; ++q) filter_value(1, q, tag, bq[q >> 2]);
     }

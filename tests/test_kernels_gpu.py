@@ -481,10 +481,15 @@ def test_prefilter_error_bound_holds_with_margin(fused_path):
     W = S.xavier_uniform(96, H, D, stream=1)
     W[::3] *= 0.01
     bias = S.normal(96, (H,), stream=3, std=0.5)
-    idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False)
+    lib = _lib.load()
+    lib.qsae_debug_set_inkernel_pilot.argtypes = [C.c_int, C.c_int]
+    lib.qsae_debug_set_inkernel_pilot(0, 0)                # this test reads the dense pilot block: separate pilot GEMM
+    try:
+        idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False)
+    finally:
+        lib.qsae_debug_set_inkernel_pilot(1, 0)
     want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
     assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)
-    lib = _lib.load()
     po, mo, pc = C.c_size_t(), C.c_size_t(), C.c_int()
     lib.qsae_debug_prefilter_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 2 + [C.POINTER(C.c_int)]
     lib.qsae_debug_prefilter_offsets(B, D, H, k, C.byref(po), C.byref(mo), C.byref(pc))

@@ -25,6 +25,9 @@ lib.qsae_debug_set_xstat_rot.argtypes = [C.c_int]
 lib.qsae_debug_set_refine_ablate.argtypes = [C.c_int]
 lib.qsae_debug_set_pilot.argtypes = [C.c_int, C.c_int]
 import os
+lib.qsae_debug_set_inkernel_pilot.argtypes = [C.c_int, C.c_int]
+if os.environ.get('QSAE_INKERNEL'):
+    lib.qsae_debug_set_inkernel_pilot(*[int(v) for v in os.environ['QSAE_INKERNEL'].split(',')])
 if os.environ.get('QSAE_PILOT'):
     lib.qsae_debug_set_pilot(*[int(v) for v in os.environ['QSAE_PILOT'].split(',')])
 
