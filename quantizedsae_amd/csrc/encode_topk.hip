@@ -42,7 +42,7 @@ static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
 static int g_inkernel_pilot = 1;   // the stationary sweep derives tau itself (no pilot GEMM / selection launches)
-static int g_inkernel_rank = 14;   // tau = this rank among the row's 32 group maxima
+static int g_inkernel_rank = 0;    // tau = this rank among the row's 32 group maxima; 0 = from k (inkernel_rank)
 static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
 static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
@@ -841,6 +841,14 @@ static bool prefilter_shape_ok(int B, int D, int H, int k) {
     return use_fused(B, D, H, k) && D % 64 == 0 && D <= kRefMaxD && (H - pilot_width(H)) > 0;
 }
 
+// Rank among the 32 group maxima (each over H/512 pilot units) that puts about max(4.6 k, 200) values of a row
+// above tau: P(group max >= tau) = r/32 = 1 - F^(H/512)  =>  expected count H (1 - F) ~ -512 ln(1 - r/32).
+static int inkernel_rank(int k) {
+    const double target = 4.6 * k > 200.0 ? 4.6 * k : 200.0;
+    int r = static_cast<int>(32.0 * (1.0 - exp(-target / 512.0)) + 0.5);
+    return r < 6 ? 6 : (r > 24 ? 24 : r);
+}
+
 static int run_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
                          int B, int D, int H, int k, int32_t* idx, float* val, char* ws, qsae_stream_t stream,
                          float* dense, int64_t dense_ld) {
@@ -915,7 +923,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         if (xstat) {
             XsArgs xa{xq + 0, Wq + static_cast<size_t>(hoff) * D, bias ? bias + hoff : nullptr, tau, margin, inv, cand, cnt,
                       B, Hs, kCandCap, hoff, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H,
-                      fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank, tau, parts, cnt_parts};
+                      fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank > 0 ? g_inkernel_rank : inkernel_rank(k), tau, parts,
+                      cnt_parts};
             rc = launch_xstat(D, xa, s, g_xstat_ablate);
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
@@ -1014,7 +1023,7 @@ extern "C" int qsae_debug_set_pilot(int div, int rank) {
 // in-kernel pilot of the stationary sweep: enable (0 = separate pilot GEMM + selection), rank among 32 group maxima
 extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
     g_inkernel_pilot = enable;
-    if (rank > 0) g_inkernel_rank = rank;
+    g_inkernel_rank = rank;                                  // 0 = derive from k
     return QSAE_OK;
 }
 

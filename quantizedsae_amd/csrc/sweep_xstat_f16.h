@@ -120,12 +120,15 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const int nstages = static_cast<int>(static_cast<long long>(part + 1) * all_stages / a.parts);   // end (absolute)
     const int cap_part = a.cap / a.parts;
     int* my_cnt = part == 0 ? a.cnt : a.cnt_parts + static_cast<size_t>(part - 1) * a.B;
-    // Iterations and blocks.  A part runs pilot_stages pilot iterations over hidden blocks 0.. (64 hidden units
-    // each), then its share [s_begin, nstages) of all blocks; iteration `it` uses LDS buffer it % 2 and bias copy
+    // Iterations and blocks.  A part runs pilot_stages pilot iterations over evenly spaced hidden blocks (64 hidden
+    // units each), then its share [s_begin, nstages) of all blocks; iteration `it` uses LDS buffer it % 2 and bias copy
     // it % 3, block(it) gives the hidden block it works on.
     const int ps = a.pilot_stages;
     const int n_iter = ps + (nstages - s_begin);
-    auto block_of = [&](int it) { return it < ps ? it : s_begin + (it - ps); };
+    // the pilot blocks are spread evenly over the hidden range (a stratified sample: robust against checkpoints
+    // whose hidden units are ordered, e.g. dead units first)
+    const int pilot_stride = ps > 0 ? all_stages / ps : 1;
+    auto block_of = [&](int it) { return it < ps ? it * pilot_stride : s_begin + (it - ps); };
     int ld = 0;                                              // next iteration to issue
     // One 1-KiB piece of iteration `ld` per call (i is a compile-time constant at every call site); wave 0 adds the
     // block's bias (kXsHT floats, lanes 0..kXsHT/4-1, 16 bytes each) to piece 0.  Three bias copies in rotation:

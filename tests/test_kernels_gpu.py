@@ -467,6 +467,25 @@ def test_prefilter_stationary_sweep_strided_dense_and_degenerate_rows(fused_path
     assert bool((buf[:, H:] == 7.0).all())                 # the fill respects the row stride
 
 
+def test_prefilter_ordered_checkpoint_keeps_the_fast_path(fused_path):
+    """Hidden units ordered by liveness (the first H/8 never fire): the stratified in-kernel pilot still finds a
+    useful threshold -- exact results and (nearly) no row in the exact fallback."""
+    from quantizedsae_amd import _lib
+    ops = _ops()
+    B, D, H, k = 600, 512, 8192, 16                        # k = int(H * 0.002), the reference's ratio
+    x = S.activations(101, B, D)
+    W = S.xavier_uniform(101, H, D, stream=1)
+    bias = S.normal(101, (H,), stream=3, std=0.02)
+    bias[: H // 8] = -50.0                                 # dead units first
+    idx, val, dense = _prefilter(ops, x, W, bias, k)
+    flagged = _lib.load().qsae_debug_last_flagged()
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
+    assert flagged <= B // 20, flagged
+
+
 def test_prefilter_error_bound_holds_with_margin(fused_path):
     """max |approx - exact chain| over the pilot block stays far below the eps_b the selection relies on
     (inputs with outliers, tiny and huge scales)."""
@@ -487,7 +506,7 @@ def test_prefilter_error_bound_holds_with_margin(fused_path):
     try:
         idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False)
     finally:
-        lib.qsae_debug_set_inkernel_pilot(1, 0)
+        lib.qsae_debug_set_inkernel_pilot(1, 0)             # (rank 0 = derived from k)
     want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
     assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val), want_val)
     po, mo, pc = C.c_size_t(), C.c_size_t(), C.c_int()
