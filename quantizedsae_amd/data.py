@@ -53,8 +53,11 @@ class HiddenStatesTorchDataset(Dataset):
     def iter_batches(self, batch_rows: int, device, world_size: int = 1, rank: int = 0) -> Iterator[torch.Tensor]:
         """This rank's contiguous slice of the chunk (``sharding.shard_rows``) in device batches."""
         s, e = shard_rows(self.cum_sizes, world_size, rank)
+        flat = self.data.reshape(self.cum_sizes, self.files_info[3])
         for a in range(s, e, batch_rows):
-            yield self.rows(a, min(a + batch_rows, e)).to(device, non_blocking=True)
+            # ship the stored dtype (fp16 dumps: half the bytes over PCIe) and widen on the device; fp16/bf16 -> fp32
+            # is exact, so the values equal the reference's host-side .float()
+            yield flat[a:min(a + batch_rows, e)].to(device, non_blocking=True).float()
 
 
 class HiddenStatesTorchDatasetInBinary(HiddenStatesTorchDataset):

@@ -303,3 +303,31 @@ def test_full_size_properties():
                                  host(model.decoder.weight), host(model.decoder.bias), n_bits=4, gamma=4.0, k=k)
     assert np.array_equal(host(recon[sel]), want["reconstruction"])
     assert np.array_equal(host(latent[sel]), want["latent"])
+
+
+def test_baseline_full_size_paths_agree():
+    """BaselineSparseAutoencoder at H=32768 on a batch large enough for the default (fp16 candidate pass) path:
+    forward(), forward_compact() and the exact-fp32 paths return the same bits; 32 rows against the oracle."""
+    D, H, B = 512, 32768, 4096
+    g = torch.Generator(device=DEV); g.manual_seed(6)
+    model = BaselineSparseAutoencoder(D, H).to(DEV).eval()
+    with torch.no_grad():
+        model.encoder[0].bias.copy_(torch.randn((H,), device=DEV, generator=g) * 0.05)
+    x = torch.randn((B, D), device=DEV, generator=g)
+    h, recon = model(x)                                     # auto -> prefilter
+    assert ((h != 0).sum(1) == model.topk).all()
+    idx, val, recon_c = model.forward_compact(x)
+    assert torch.equal(recon_c, recon)
+    dense_c = torch.zeros_like(h).scatter_(1, idx.long(), val)
+    assert torch.equal(dense_c, h)
+    for path in ("fused", "inplace"):
+        model.latent_path = path
+        h2, r2 = model(x)
+        assert torch.equal(h2, h) and torch.equal(r2, recon), path
+        del h2, r2
+    model.latent_path = "auto"
+    sel = torch.arange(0, B, B // 32, device=DEV)
+    want = oracle.baseline_forward(host(x[sel]), host(model.encoder[0].weight), host(model.encoder[0].bias),
+                                   host(model.decoder.weight), host(model.decoder.bias), k=model.topk)
+    assert np.array_equal(host(h[sel]), want["latent"])
+    assert np.array_equal(host(recon[sel]), want["reconstruction"])
