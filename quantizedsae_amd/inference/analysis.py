@@ -188,12 +188,14 @@ def compute_activation_stats(sae: SAEWrapper, loader: Iterable[Any], *, token_id
                     rows = torch.arange(B, device=dev).unsqueeze(1).expand_as(idx)[on]
                     _tokens_per_feature(idx[on].long(), batch_tok.to(dev)[rows], H, tokens_per_feature)
             else:
-                # threshold variants: hundreds of active units per row; the mask product is formed densely on
-                # the device, as the reference's analyze_dataset does (dynamic_analysis.py:405-415)
+                # threshold variants: hundreds to thousands of active units per row, so the mask product is formed
+                # densely like the reference's analyze_dataset does (dynamic_analysis.py:405-415) -- with the exact-fp32
+                # MFMA contraction of this package (qsae_encode_dense)
                 mask = _activation_mask(sae, x).to(dev)
                 counts += mask.sum(dim=0)
-                mf = mask.float()
-                coact += torch.matmul(mf.t(), mf).to(torch.int32)
+                pad = (-mask.shape[0]) % 4                               # the contraction wants K % 4 == 0: zero rows add nothing
+                mt = torch.nn.functional.pad(mask.t().float(), (0, pad)).contiguous()   # [H, B(+pad)]: both GEMM operands
+                coact += ops.encode_dense(mt, mt, None, ops.ACT_NONE).to(torch.int32)   # exact: 0/1 products, sums < 2^24
                 if with_tokens:
                     nz = mask.nonzero(as_tuple=False)
                     _tokens_per_feature(nz[:, 1], batch_tok.to(dev)[nz[:, 0]], H, tokens_per_feature)
