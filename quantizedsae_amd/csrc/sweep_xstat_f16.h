@@ -1,25 +1,30 @@
 // sweep_xstat_f16.h -- the fp16 candidate sweep with the activation panel stationary in registers.
 //
-// Role: step 4 of the prefilter pipeline (encode_topk.hip).  For every activation row b and every swept
+// Role: the candidate pass of the prefilter pipeline (encode_topk.hip).  For every activation row b and every
 // hidden unit h it forms the approximate latent  v = fma(sum_k xq[b,k] wq[h,k], inv[b], bias[h])  with
 // v_mfma_f32_32x32x16_f16 and appends (v, h) to the row's candidate list when !(v < tau[b] - margin[b]).
 // It returns no values of its own: the refine step recomputes every survivor with the exact fp32 chain.
+// The same launch (i) derives tau from a pilot pass over a stratified H/16 sample of the hidden units
+// (pilot_stages > 0), (ii) writes the zeros of the dense [B, H] latent, whose HBM traffic it hides.
 //
-// Data movement (the point of this kernel; the generic LDS-DMA GEMM stages BOTH operands for every tile
-// and is bound by ~20 GB/s/CU of DMA, 3.0 ms on the headline shape):
+// Data movement (the generic LDS-DMA GEMM stages BOTH operands for every tile and is bound by ~20 GB/s/CU of
+// DMA, 3.0 ms on the headline shape):
 //   * a workgroup owns 256 activation rows for the whole launch: wave w keeps the B-operand fragments of
 //     rows 32w..32w+31 for all of K in registers (D = 512: 32 k-blocks x 4 VGPRs = 128 VGPRs), loaded once;
-//   * only the fp16 weights stream: HT = 64 hidden rows (D*2 bytes each) per stage, 2 stages in LDS,
-//     written by global_load_lds_dwordx4 one stage ahead; every workgroup streams the same rows in the
-//     same order, so after the first toucher in an XCD the stream is L2 hits;
+//   * only the fp16 weights stream: 64 hidden rows (D*2 bytes each) per iteration, 2 buffers in LDS, written by
+//     global_load_lds_dwordx4 one iteration ahead, one 1-KiB piece between two MFMA groups; every workgroup
+//     streams the same rows in the same order, so after the first toucher in an XCD the stream is L2 hits;
 //   * staged bytes per MFMA FLOP are 1/256 B (256 x 256 tile: 1/128, 256 x 128: 1/85).
-// LDS image of a stage: row r = CPR 16-byte chunks; chunk j sits at position j ^ (r & 15), applied on the
+// LDS image of a buffer: row r = CPR 16-byte chunks; chunk j sits at position j ^ (r & 15), applied on the
 // DMA source address and on the fragment read: the four 16-lane groups of a ds_read_b128 (MI355X guide,
 // LDS table) each see 16 rows that are distinct mod 16, i.e. 16 distinct bank groups.
-// Synchronisation: one s_waitcnt vmcnt(0) + s_barrier per stage.  Nothing but the DMA and the (rare)
-// candidate flushes uses the vector memory counter inside the loop: the stage's bias is DMA'd into LDS
-// with the weights, hits collect in per-lane LDS record slots and are flushed (list lengths in registers)
-// at the top of the next stage, *before* that stage's DMA.
+// One iteration: flush of the previous records -> [32 MFMAs of row tile 0 | DMA pieces of the next block |
+// filter of the previous row tile 1] -> [32 MFMAs of row tile 1 | fill stores | filter of row tile 0] ->
+// s_waitcnt vmcnt(#fill stores) -> s_barrier.  vmcnt retires loads, stores and LDS-DMA in issue order, and
+// the fill stores are the youngest operations of an iteration: the wait retires the DMA without waiting for
+// the stores.  Nothing else uses the vector memory counter inside the loops: the block's bias is DMA'd into
+// LDS with the weights, hits collect in per-lane LDS record slots and are flushed (list lengths in registers)
+// at the top of the next iteration, before its DMA.
 #pragma once
 
 #include "gemm_mfma_f32_dma.h"
@@ -36,7 +41,7 @@ struct XsArgs {
     const _Float16* __restrict__ xq;      // [B][D] scaled fp16 activations
     const _Float16* __restrict__ wq;      // [Hs][D] fp16 weights of the swept hidden units
     const float* __restrict__ bias;       // [Hs] or nullptr
-    const float* __restrict__ tau;        // [B]
+    const float* __restrict__ tau;        // [B] (read only when pilot_stages == 0)
     const float* __restrict__ margin;     // [B]
     const float* __restrict__ inv;        // [B]
     uint2* __restrict__ cand;             // [B][cap]
@@ -48,7 +53,7 @@ struct XsArgs {
     long long dense_ld;
     int H;                   // columns of the dense latent (all of them are filled, not only the swept ones)
     int fill_cw;             // 1-KiB pieces (256 columns of one row) a wave fills per stage
-    int pilot_stages;        // > 0: the kernel derives tau itself from the first pilot_stages * 64 hidden units (see below)
+    int pilot_stages;        // > 0: the kernel derives tau itself from pilot_stages evenly spaced 64-unit blocks (see below)
     int pilot_rank;          //   tau = pilot_rank-th largest of the row's 32 group maxima
     float* tau_out;          //   [B] tau, for the refine step's validity check
     int parts;               // hidden-range split (gridDim.y): part p sweeps stages [p*n/parts, (p+1)*n/parts),
