@@ -41,6 +41,8 @@ constexpr int kFusedMinHidden = 8192;
 static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
 static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
 static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
+static int g_fuse_xprep = 0;       // 1: the stationary sweep scales / converts the activations in its prologue (no gain
+                                   // measured: the prologue costs what the 0.07 ms preparation launch saves)
 static int g_inkernel_pilot = 1;   // the stationary sweep derives tau itself (no pilot GEMM / selection launches)
 static int g_inkernel_rank = 0;    // tau = this rank among the row's 32 group maxima; 0 = from k (inkernel_rank)
 static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
@@ -498,15 +500,6 @@ pref_w_stats_kernel(const float* __restrict__ W, const float* __restrict__ bias,
     }
 }
 
-__device__ __forceinline__ float pow2_scale_for(float maxabs) {
-    // power of two s with maxabs * s in [64, 128); 1 for zero, 0 (unusable) for non-finite input
-    if (!(maxabs == maxabs) || maxabs == __builtin_huge_valf()) return 0.f;
-    if (maxabs == 0.f) return 1.f;
-    int e;
-    (void)frexpf(maxabs, &e);                   // maxabs = m * 2^e, m in [0.5, 1)
-    return ldexpf(1.0f, 7 - e);
-}
-
 __global__ void __launch_bounds__(256)
 pref_w_cast_kernel(const float* __restrict__ W, long long n, float* __restrict__ meta, _Float16* __restrict__ Wq) {
     const float sw = pow2_scale_for(meta[3]);
@@ -534,26 +527,12 @@ pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __res
         mx = (o > mx || o != o) ? o : mx;
         ss += __shfl_xor(ss, off, 64);
     }
-    const float sw = meta[0], wn = meta[1], bmax = meta[2];
-    const float sx = pow2_scale_for(mx);
+    float sx, iv, mg;
+    pref_row_params(mx, ss, D, meta[0], meta[1], meta[2], sx, iv, mg);
     for (int d = lane; d < D; d += 64) xq[static_cast<int64_t>(row) * D + d] = static_cast<_Float16>(xr[d] * sx);
     if (lane == 0) {
-        const float nrm = sqrtf(ss) * 1.000001f;
-        float eps = __builtin_huge_valf();            // non-finite row or weights: everything is a candidate -> flagged
-        float iv = 0.f;
-        if (sx > 0.f && sw > 0.f && nrm < 3.0e38f && wn < 3.0e38f) {
-            const float sd = sqrtf(static_cast<float>(D));
-            const float u = 5.9604645e-8f;                              // 2^-24
-            const float c1 = 9.78e-4f + 5.0f * D * u;                   // fp16 input roundings + 4x fp32 accumulation + exact chain
-            eps = c1 * nrm * wn                                         // relative to sum_k |x_k||w_k| <= ||x|| ||w||
-                  + (D + 8.0f) * u * bmax                               // every chain step (and the final fma) also rounds at the bias' magnitude
-                  + 8.0f * u * nrm * wn
-                  + 6.0e-8f * sd * (wn / sx + nrm / sw);                // fp16 subnormal flushing of tiny elements
-            eps *= 1.0001f;
-            iv = (1.0f / sx) * (1.0f / sw);                            // powers of two: exact
-        }
         inv[row] = iv;
-        margin[row] = 2.0f * eps;
+        margin[row] = mg;
     }
 }
 
@@ -885,9 +864,13 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     const int xs_iters = xstat ? (Hs / kXsHT) / parts + (inkernel ? P / kXsHT : 0) : 0;
     const int fill_cw = xs_iters > 0 ? (32 * (H / 256) / parts + xs_iters - 1) / xs_iters : 0;   // 1-KiB pieces per wave and iteration
     const bool fill_in_sweep = xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
-    // 1. fp16 copy of the batch + per-row scale and error margin
-    hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
-    QSAE_LAUNCH_CHECK();
+    // 1. fp16 copy of the batch + per-row scale and error margin (the stationary sweep with the in-kernel pilot does
+    //    this in its own prologue, straight into registers)
+    const bool fuse_prep = inkernel && g_fuse_xprep;
+    if (!fuse_prep) {
+        hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
+        QSAE_LAUNCH_CHECK();
+    }
     const int Kw = D / 2;                                    // 4-byte words per fp16 row
     const float* xq_w = reinterpret_cast<const float*>(xq);
     const float* wq_w = reinterpret_cast<const float*>(Wq);
@@ -923,8 +906,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         if (xstat) {
             XsArgs xa{xq + 0, Wq + static_cast<size_t>(hoff) * D, bias ? bias + hoff : nullptr, tau, margin, inv, cand, cnt,
                       B, Hs, kCandCap, hoff, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H,
-                      fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank > 0 ? g_inkernel_rank : inkernel_rank(k), tau, parts,
-                      cnt_parts};
+                      fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank > 0 ? g_inkernel_rank : inkernel_rank(k), tau,
+                      fuse_prep ? x : nullptr, meta, inv, margin, parts, cnt_parts};
             rc = launch_xstat(D, xa, s, g_xstat_ablate);
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
@@ -1022,6 +1005,8 @@ extern "C" int qsae_debug_set_pilot(int div, int rank) {
 
 // in-kernel pilot of the stationary sweep: enable (0 = separate pilot GEMM + selection), rank among 32 group maxima
 extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
+    g_fuse_xprep = enable >= 2 ? 1 : 0;                      // 2 = in-kernel pilot + activation preparation fused into the sweep prologue
+    enable = enable ? 1 : 0;
     g_inkernel_pilot = enable;
     g_inkernel_rank = rank;                                  // 0 = derive from k
     return QSAE_OK;

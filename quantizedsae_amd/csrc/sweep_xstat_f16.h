@@ -28,6 +28,7 @@
 #pragma once
 
 #include "gemm_mfma_f32_dma.h"
+#include "prefilter_common.h"
 
 namespace qsae {
 
@@ -56,6 +57,10 @@ struct XsArgs {
     int pilot_stages;        // > 0: the kernel derives tau itself from pilot_stages evenly spaced 64-unit blocks (see below)
     int pilot_rank;          //   tau = pilot_rank-th largest of the row's 32 group maxima
     float* tau_out;          //   [B] tau, for the refine step's validity check
+    const float* x32;        // non-null: fp32 activations [B][D]; the kernel scales / converts them itself (no xq) and
+    const float* meta;       //   writes inv / margin for the refine step; meta = {s_w, max ||W_h||, max |bias|}
+    float* inv_out;
+    float* margin_out;
     int parts;               // hidden-range split (gridDim.y): part p sweeps stages [p*n/parts, (p+1)*n/parts),
     int* cnt_parts;          //   appends to the row's list segment [p*cap/parts, ...) and counts in cnt_parts[(p-1)*B + row]
 };
@@ -85,17 +90,53 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const bool row_ok = row < a.B;
     const int crow = row_ok ? row : a.B - 1;
 
-    const float margin_row = a.margin[crow];
-    const float thr = a.pilot_stages > 0 ? 0.0f : a.tau[crow] - margin_row;      // in-kernel pilot: set after the pilot pass
-    const float inv = a.inv[crow];
-
+    float margin_row, inv;
     // ---- stationary operand: this lane's 8 halves of every k-block of its activation row -----------
     f16x8 xf[KB];
-    {
+    if (a.x32) {
+        // fused preparation: the row's max |x| and sum x^2 (this lane holds half of the row, the partner lane the
+        // other half), its power-of-two scale, error budget, and the fp16 fragments straight into registers
+        const float* xr = a.x32 + static_cast<int64_t>(crow) * D + 8 * lane_half;
+        float mx = 0.f, ss = 0.f;
+#pragma unroll 4
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(xr + 16 * kb), p1 = *reinterpret_cast<const f32x4*>(xr + 16 * kb + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? p0[e] : p1[e - 4];
+                const float av = fabsf(v);
+                mx = (av > mx || av != av) ? av : mx;       // NaN propagates
+                ss = fmaf(v, v, ss);
+            }
+        }
+        {
+            const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            const float mo = __uint_as_float(lane_half ? sm[0] : sm[1]);
+            mx = (mo > mx || mo != mo) ? mo : mx;
+            const auto sq = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+            const float so = __uint_as_float(lane_half ? sq[0] : sq[1]);
+            ss = lane_half ? so + ss : ss + so;              // same operand order in both lanes: identical sums
+        }
+        float sx;
+        pref_row_params(mx, ss, D, a.meta[0], a.meta[1], a.meta[2], sx, inv, margin_row);
+        if (blockIdx.y == 0 && row_ok && lane_half == 0) {
+            a.inv_out[row] = inv;
+            a.margin_out[row] = margin_row;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(xr + 16 * kb), p1 = *reinterpret_cast<const f32x4*>(xr + 16 * kb + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[kb][e] = static_cast<_Float16>((e < 4 ? p0[e] : p1[e - 4]) * sx);
+        }
+    } else {
+        margin_row = a.margin[crow];
+        inv = a.inv[crow];
         const _Float16* xr = a.xq + static_cast<int64_t>(crow) * D + 8 * lane_half;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) xf[kb] = *reinterpret_cast<const f16x8*>(xr + 16 * kb);
     }
+    const float thr = a.pilot_stages > 0 ? 0.0f : a.tau[crow] - margin_row;      // in-kernel pilot: set after the pilot pass
 
     // ---- DMA addressing: instruction i of this wave covers chunks (wave*IPW + i)*64 .. +63 ---------
     typedef const __attribute__((address_space(1))) void* gptr_t;
