@@ -348,9 +348,14 @@ static int run_flagged_rows(const float* x, const float* W, const float* bias, i
                             bool kperm, float* dense = nullptr, int64_t dense_ld = 0) {
     hipStream_t s = as_stream(stream);
     int* flags = reinterpret_cast<int*>(ws + L.flags);
-    int nflag = 0;
-    QSAE_HIP(hipMemcpyAsync(&nflag, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    // the flagged-row count comes back through a pinned word (one per host thread, allocated on first use): a
+    // pageable destination makes the runtime stage the copy and lengthens the only host round trip of the call
+    static thread_local int* pinned = nullptr;
+    if (!pinned) QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
+    *pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
     QSAE_HIP(hipStreamSynchronize(s));
+    const int nflag = *pinned;
     g_last_flagged = nflag;
     if (nflag <= 0) return QSAE_OK;
     float* fx = reinterpret_cast<float*>(ws + L.fx);
