@@ -301,12 +301,26 @@ select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
 }
 
 // ---- fallback helpers ---------------------------------------------------------------------------
+static int kSpecRows = 32;         // flagged rows the fallback handles before the host knows their count (debug-tunable; 0 = wait for the count first)
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, int n, int D, float* __restrict__ dst) {
     const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= static_cast<long long>(n) * D) return;
     const int r = static_cast<int>(gid / D), c = static_cast<int>(gid % D);
     dst[gid] = src[static_cast<long long>(rows[r]) * D + c];
+}
+
+// Variants with the row count read on the device (min(*count, cap) rows): the first chunk of the fallback is
+// enqueued before the host knows the count.  Unused rows of dst take activation row r itself (cap <= B): defined,
+// ordinary data -- all-zero rows would tie everywhere and send the top-k kernel down its slow tie path.
+__global__ void __launch_bounds__(256)
+gather_rows_dev_kernel(const float* __restrict__ src, const int* __restrict__ rows, const int* __restrict__ count,
+                       int cap, int D, float* __restrict__ dst) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(cap) * D) return;
+    const int n = *count < cap ? *count : cap;
+    const int r = static_cast<int>(gid / D), c = static_cast<int>(gid % D);
+    dst[gid] = src[static_cast<long long>(r < n ? rows[r] : r) * D + c];
 }
 
 __global__ void __launch_bounds__(256)
@@ -319,6 +333,19 @@ scatter_topk_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ 
     idx[static_cast<long long>(rows[r]) * k + j] = sidx[gid];
     val[static_cast<long long>(rows[r]) * k + j] = sval[gid];
     // optional: the row's entries of an already zero-filled dense latent
+    if (dense && sidx[gid] >= 0 && sidx[gid] < H) dense[static_cast<long long>(rows[r]) * dense_ld + sidx[gid]] = sval[gid];
+}
+
+__global__ void __launch_bounds__(256)
+scatter_topk_dev_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sval, const int* __restrict__ rows,
+                        const int* __restrict__ count, int cap, int k, int32_t* __restrict__ idx, float* __restrict__ val,
+                        float* __restrict__ dense, int64_t dense_ld, int H) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int n = *count < cap ? *count : cap;
+    if (gid >= static_cast<long long>(n) * k) return;
+    const int r = static_cast<int>(gid / k), j = static_cast<int>(gid % k);
+    idx[static_cast<long long>(rows[r]) * k + j] = sidx[gid];
+    val[static_cast<long long>(rows[r]) * k + j] = sval[gid];
     if (dense && sidx[gid] >= 0 && sidx[gid] < H) dense[static_cast<long long>(rows[r]) * dense_ld + sidx[gid]] = sval[gid];
 }
 
@@ -348,21 +375,42 @@ static int run_flagged_rows(const float* x, const float* W, const float* bias, i
                             bool kperm, float* dense = nullptr, int64_t dense_ld = 0) {
     hipStream_t s = as_stream(stream);
     int* flags = reinterpret_cast<int*>(ws + L.flags);
-    // the flagged-row count comes back through a pinned word (one per host thread, allocated on first use): a
-    // pageable destination makes the runtime stage the copy and lengthens the only host round trip of the call
-    static thread_local int* pinned = nullptr;
-    if (!pinned) QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
-    *pinned = 0;
-    QSAE_HIP(hipMemcpyAsync(pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    QSAE_HIP(hipStreamSynchronize(s));
-    const int nflag = *pinned;
-    g_last_flagged = nflag;
-    if (nflag <= 0) return QSAE_OK;
     float* fx = reinterpret_cast<float*>(ws + L.fx);
     float* flat = reinterpret_cast<float*>(ws + L.flat);
     int32_t* fidx = reinterpret_cast<int32_t*>(ws + L.fidx);
     float* fval = reinterpret_cast<float*>(ws + L.fval);
-    for (int f0 = 0; f0 < nflag; f0 += kChunkRows) {
+    // The flagged-row count comes back through a pinned word (one per host thread, allocated on first use; a pageable
+    // destination makes the runtime stage the copy).  The host waits for THAT COPY only (an event right behind it),
+    // and meanwhile the GPU already runs the exact fallback for the first kSpecRows flagged rows with the count read
+    // on the device: a typical batch has a handful of flagged rows, so the device never idles through the host round
+    // trip and the caller's next launches queue up behind work that is still running.
+    static thread_local int* pinned = nullptr;
+    static thread_local hipEvent_t copied = nullptr;
+    if (!pinned) QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
+    if (!copied) QSAE_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+    *pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipEventRecord(copied, s));
+    const int spec = B < kSpecRows ? B : kSpecRows;
+    if (spec > 0) {
+        const long long tot = static_cast<long long>(spec) * D;
+        hipLaunchKernelGGL(gather_rows_dev_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x,
+                           flags + 1, flags, spec, D, fx);
+        QSAE_LAUNCH_CHECK();
+        int rc = dense_latent(fx, W, bias, spec, D, H, flat, H, stream, kperm);
+        if (rc != QSAE_OK) return rc;
+        rc = qsae_topk_rows(flat, H, spec, H, k, fidx, fval, 0, stream);
+        if (rc != QSAE_OK) return rc;
+        const long long tk = static_cast<long long>(spec) * k;
+        hipLaunchKernelGGL(scatter_topk_dev_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx,
+                           fval, flags + 1, flags, spec, k, idx, val, dense, dense_ld, H);
+        QSAE_LAUNCH_CHECK();
+    }
+    QSAE_HIP(hipEventSynchronize(copied));
+    const int nflag = *pinned;
+    g_last_flagged = nflag;
+    if (nflag <= spec) return QSAE_OK;
+    for (int f0 = spec; f0 < nflag; f0 += kChunkRows) {
         const int n = (nflag - f0) < kChunkRows ? (nflag - f0) : kChunkRows;
         const int* rows = flags + 1 + f0;
         const long long tot = static_cast<long long>(n) * D;
@@ -1009,6 +1057,11 @@ extern "C" int qsae_debug_set_pilot(int div, int rank) {
 }
 
 // in-kernel pilot of the stationary sweep: enable (0 = separate pilot GEMM + selection), rank among 32 group maxima
+extern "C" int qsae_debug_set_spec_rows(int rows) {
+    kSpecRows = rows;
+    return QSAE_OK;
+}
+
 extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
     g_fuse_xprep = enable >= 2 ? 1 : 0;                      // 2 = in-kernel pilot + activation preparation fused into the sweep prologue
     enable = enable ? 1 : 0;
