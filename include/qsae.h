@@ -114,7 +114,10 @@ int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, i
  * val and dense are bit-identical to qsae_encode_topk_latent.  Rows the bound cannot serve (non-finite
  * inputs, overflowing lists) go through the exact kernels.  Wq/meta come from qsae_prefilter_pack_w
  * (once per checkpoint: Wq = H*D fp16, meta = 4 device floats).  D % 64 == 0, D <= 2048; other shapes
- * return QSAE_ERR_UNSUPPORTED (use qsae_encode_topk_latent).  dense may be NULL. */
+ * return QSAE_ERR_UNSUPPORTED (use qsae_encode_topk_latent).  dense may be NULL.  For D in {128, 256, 512} the
+ * candidate pass is one launch (activation rows stationary in registers, fp16 weights streamed once per workgroup)
+ * that also derives the row thresholds and writes the zeros of `dense`; the survivors are written by the refinement.
+ * One host round trip per call (the count of rows sent through the exact kernels). */
 size_t qsae_prefilter_w_bytes(int H, int D);
 int qsae_prefilter_pack_w(const float* W, const float* bias, int H, int D, void* Wq, float* meta,
                           qsae_stream_t stream);
