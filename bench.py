@@ -172,12 +172,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU path)")
-    device = torch.device("cuda", local_rank)
+    # QSAE_BENCH_BACKEND=gloo is a rehearsal switch for a one-GPU box (ranks share the card, the three scalar
+    # reductions go over gloo); the driver's multi-GPU runs use the default, RCCL with one card per rank
+    backend = os.environ.get("QSAE_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from quantizedsae_amd import ops, sharding
     model = build_model(device)

@@ -41,6 +41,8 @@ def reduce_mse(sq_err_sum: torch.Tensor, n_elements: int, group=None) -> float:
     pair = torch.stack([sq_err_sum.detach().to(torch.float64).reshape(()),
                         torch.tensor(float(n_elements), dtype=torch.float64, device=sq_err_sum.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "gloo":
+            pair = pair.cpu()
         dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
     total, count = float(pair[0].item()), float(pair[1].item())
     if count == 0:
@@ -52,6 +54,8 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None, group=No
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return float(value)
+    if dist.get_backend(group) == "gloo":
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
