@@ -185,6 +185,30 @@ int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H
                            const int32_t* level_sizes, const uint32_t* codes2t, const float* scale,
                            const float* bias, int allow_bias, float* levels,
                            unsigned long long* l0_counts, qsae_stream_t stream);
+/* The same z bits as qsae_encode_bits (z = sigmoid(x W^T + b) > 0.5, sae/quantized_matryoshka.py:97-99,217-220)
+ * without computing every latent in fp32: the fp16 candidate sweep of the prefilter (tau = the fp32 cutoff of
+ * sigmoid > 0.5, Wq/meta from qsae_prefilter_pack_w) lists the latents within 2 eps_b of the cutoff or above it;
+ * latents above cutoff + eps_b get bit 1 directly, the few inside the band are re-evaluated with the exact fp32
+ * chain.  Bit-identical to qsae_encode_bits.  Rows with more than 2048 listed latents (dense activations) and
+ * rows with non-finite inputs are recomputed by the exact dense kernel; *flagged_rows (host int, may be NULL)
+ * receives their count so that a caller can route a dense-regime model to qsae_encode_bits.  D in {128,256,512},
+ * H % 64 == 0, else QSAE_ERR_UNSUPPORTED.  One host round trip per call. */
+size_t qsae_encode_bits_prefilter_workspace_bytes(int B, int D, int H);
+int qsae_encode_bits_prefilter(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                               int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                               size_t workspace_bytes, int* flagged_rows, qsae_stream_t stream);
+/* Hidden-major dictionary for the sparse decoder: codes_rows[j][ceil(D/16)] uint32, 2-bit two's-complement
+ * fields of S_j/2 (same S as qsae_pack_matryoshka). */
+int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,
+                              qsae_stream_t stream);
+/* qsae_decode_matryoshka evaluated on the active units only (ascending walk over the row's z bits, one fmaf
+ * per active unit and output column): the same chain as the dense kernel, whose z = 0 terms leave the
+ * accumulator unchanged -- bit-identical levels and l0_counts.  Pays off below ~5 % active units.
+ * D in {64,128,256,512,1024}; H % 32 == 0 (level boundaries need no alignment here). */
+int qsae_decode_matryoshka_sparse(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
+                                  const int32_t* level_sizes, const uint32_t* codes_rows, const float* scale,
+                                  const float* bias, int allow_bias, float* levels,
+                                  unsigned long long* l0_counts, qsae_stream_t stream);
 /* zbits[b][w] bit j = dense[b][32w+j] > thr -- the `latent > 0.5` binarisation applied to an
  * already materialised sigmoid latent (sae/quantized_matryoshka.py:97-99 when the decoder is
  * called directly, scripts/analysis/dynamic_analysis.py:51,66). */

@@ -48,6 +48,10 @@ SIGNATURES = {
     "qsae_matryoshka_sizes": (_i, [_i, _i, _vp]),
     "qsae_pack_matryoshka": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "qsae_decode_matryoshka": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "qsae_encode_bits_prefilter_workspace_bytes": (_sz, [_i, _i, _i]),
+    "qsae_encode_bits_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, C.POINTER(_i), _vp]),
+    "qsae_pack_matryoshka_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "qsae_decode_matryoshka_sparse": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_pack_bits_gt": (_i, [_vp, _i64, _i, _i, _f, _vp, _i64, _vp]),
     "qsae_sq_err_sum": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "qsae_activation_counts": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -192,6 +192,119 @@ count_bits_kernel(const uint32_t* __restrict__ zbits, int64_t words_ld, int B, i
     }
 }
 
+// ---- matryoshka, sparse activations --------------------------------------------------------------
+// With few active units per row (a trained dictionary: tens to hundreds of 32768) the dense contraction spends
+// 2 H D FLOP per row on zeros.  The sparse form walks the row's z bits in ascending hidden order and adds
+// scale_j * S_j for the active units only: the same fmaf chain as the MFMA kernel above, whose terms with
+// z = 0 leave the accumulator unchanged, so the results are bit-identical.  Dictionary in hidden-major order
+// (codes_rows[j][D/16]: one 128-byte line per unit at D = 512), a wave per activation row, every lane owns
+// D/64 consecutive output columns; level outputs are written whenever the walk crosses a level boundary.
+constexpr int kSpWaves = 4;
+constexpr int kSpRound = 64 * 32;          // hidden units whose bits one round of the walk loads (one word per lane)
+
+__global__ void __launch_bounds__(256)
+pack_matryoshka_rows_kernel(const float* __restrict__ w, const float* __restrict__ wm, int H, int D, int row_words,
+                            uint32_t* __restrict__ codes_rows) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(H) * row_words) return;
+    const int j = static_cast<int>(gid / row_words), wi = static_cast<int>(gid % row_words);
+    uint32_t word = 0;
+    for (int f = 0; f < 16; ++f) {
+        const int d = wi * 16 + f;
+        if (d >= D) break;
+        const long long o = static_cast<long long>(j) * D + d;
+        const int half = (sig_ge_half(w[o]) ? 1 : -1) + (sig_ge_half(wm[o]) ? 1 : -1);   // -2, 0, 2
+        const uint32_t code = half == 0 ? 0u : (half > 0 ? 1u : 3u);
+        word |= code << (2 * f);
+    }
+    codes_rows[gid] = word;
+}
+
+template <int FPL>   // output columns per lane: D = 64 * FPL
+__global__ void __launch_bounds__(64 * kSpWaves)
+decode_matryoshka_sparse_kernel(const uint32_t* __restrict__ zbits, int64_t words_ld, int B, int H,
+                                const uint32_t* __restrict__ codes_rows, const float* __restrict__ scale, LevelTable lv,
+                                const float* __restrict__ bias, float* __restrict__ levels, int64_t level_stride) {
+    constexpr int D = 64 * FPL;
+    constexpr int ROW_WORDS = D / 16;
+    __shared__ uint16_t lists[kSpWaves][kSpRound];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kSpWaves + wave;
+    if (b >= B) return;
+    uint16_t* list = lists[wave];
+    typedef const __attribute__((address_space(4))) float* cflt_t;
+    float acc[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) acc[f] = 0.0f;
+    float bcol[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) bcol[f] = bias ? bias[lane * FPL + f] : 0.0f;
+    // this lane's FPL two-bit fields sit in word (lane*FPL)/16 of a dictionary row, from bit 2*((lane*FPL)%16) on
+    const int wsel = (lane * FPL) / 16;
+    const int wshift = 2 * ((lane * FPL) % 16);
+    int level = 0;
+    auto write_level = [&](int lvl) {
+        float* out = levels + static_cast<int64_t>(lvl) * level_stride + static_cast<int64_t>(b) * D + lane * FPL;
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) out[f] = acc[f] + bcol[f];
+    };
+    auto add_unit = [&](int j, uint32_t cw, float a) {
+        const int w = static_cast<int>(cw >> wshift);
+#pragma unroll
+        for (int f = 0; f < FPL; ++f)
+            acc[f] = fmaf(a, static_cast<float>(2 * sbfe_i32(w, 2 * f, 2)), acc[f]);
+    };
+    const int words = H / 32;
+    const uint32_t* zrow = zbits + static_cast<int64_t>(b) * words_ld;
+    for (int w0 = 0; w0 < words; w0 += 64) {
+        uint32_t word = (w0 + lane < words) ? zrow[w0 + lane] : 0u;
+        // ascending list of the round's active units: exclusive prefix of the per-lane popcounts
+        const int mine = __popc(word);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) continue;
+        int pos = incl - mine;
+        while (word) {
+            const int bit = __builtin_ctz(word);
+            list[pos++] = static_cast<uint16_t>(lane * 32 + bit);
+            word &= word - 1u;
+        }
+        asm volatile("" ::: "memory");                       // one wave's LDS operations execute in order
+        const int base = w0 * 32;
+        int t = 0;
+        while (t < total) {
+            // four units at a time while they stay inside the current level
+            if (t + 4 <= total && base + list[t + 3] < lv.end[level]) {
+                int j[4];
+                uint32_t cw[4];
+                float a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    j[u] = __builtin_amdgcn_readfirstlane(base + list[t + u]);
+                    cw[u] = codes_rows[static_cast<int64_t>(j[u]) * ROW_WORDS + wsel];
+                    a[u] = ((cflt_t)scale)[j[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) add_unit(j[u], cw[u], a[u]);
+                t += 4;
+            } else {
+                const int j = __builtin_amdgcn_readfirstlane(base + list[t]);
+                while (level < lv.n - 1 && j >= lv.end[level]) write_level(level++);
+                add_unit(j, codes_rows[static_cast<int64_t>(j) * ROW_WORDS + wsel], ((cflt_t)scale)[j]);
+                t += 1;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    while (level < lv.n) write_level(level++);
+}
+
 static int make_levels(int H, int n_bits, float abs_range, const int32_t* level_sizes, LevelTable& lv) {
     int32_t sizes[kMaxLevels];
     if (level_sizes) {
@@ -343,4 +456,56 @@ extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, i
     }
     typename EpiLevels<128, 128>::Args ea{lv, allow_bias ? bias : nullptr, levels, static_cast<int64_t>(B) * D};
     return run_matryoshka<128, 128, 32>(zbits, words_ld, B, H, D, codes2t, scale, ea, s);
+}
+
+extern "C" int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,
+                                         qsae_stream_t stream) {
+    QSAE_CHECK_ARG(H > 0 && D > 0 && w && wm && codes_rows, "H > 0, D > 0, non-null pointers");
+    const int row_words = (D + 15) / 16;
+    const long long total = static_cast<long long>(H) * row_words;
+    hipLaunchKernelGGL(pack_matryoshka_rows_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w, wm, H, D, row_words, codes_rows);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+extern "C" int qsae_decode_matryoshka_sparse(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
+                                             const int32_t* level_sizes, const uint32_t* codes_rows, const float* scale,
+                                             const float* bias, int allow_bias, float* levels,
+                                             unsigned long long* l0_counts, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0 && D > 0, "B >= 0, H > 0, D > 0 required");
+    QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= kMaxLevels, "1 <= n_bits <= 8 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(zbits && codes_rows && scale && levels, "null pointer");
+    QSAE_CHECK_ARG(words_ld >= (H + 31) / 32, "words_ld < ceil(H/32)");
+    QSAE_CHECK_SUPPORTED(H % 32 == 0, "H must be a multiple of 32 (pad the dictionary)");
+    QSAE_CHECK_SUPPORTED(D == 64 || D == 128 || D == 256 || D == 512 || D == 1024, "D must be 64, 128, 256, 512 or 1024");
+    LevelTable lv;
+    const int rc = make_levels(H, n_bits, 1.0f, level_sizes, lv);
+    if (rc != QSAE_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    if (l0_counts) {
+        QSAE_HIP(hipMemsetAsync(l0_counts, 0, sizeof(unsigned long long) * n_bits, s));
+        const int words = H / 32;
+        long long blocks = (static_cast<long long>(B) * words + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(count_bits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, zbits, words_ld, B,
+                           words, lv, l0_counts);
+        QSAE_LAUNCH_CHECK();
+    }
+    const dim3 grid((B + kSpWaves - 1) / kSpWaves), block(64 * kSpWaves);
+    const float* bp = allow_bias ? bias : nullptr;
+    const int64_t ls = static_cast<int64_t>(B) * D;
+#define QSAE_SP_LAUNCH(F) hipLaunchKernelGGL(decode_matryoshka_sparse_kernel<F>, grid, block, 0, s, zbits, words_ld, B, H, \
+                                             codes_rows, scale, lv, bp, levels, ls)
+    switch (D / 64) {
+        case 1: QSAE_SP_LAUNCH(1); break;
+        case 2: QSAE_SP_LAUNCH(2); break;
+        case 4: QSAE_SP_LAUNCH(4); break;
+        case 8: QSAE_SP_LAUNCH(8); break;
+        default: QSAE_SP_LAUNCH(16); break;
+    }
+#undef QSAE_SP_LAUNCH
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
 }

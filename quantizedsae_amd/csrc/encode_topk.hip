@@ -1002,6 +1002,265 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     return QSAE_OK;
 }
 
+// ---- threshold bits from the candidate sweep: z = (sigmoid(x W^T + b) > 0.5), exact ---------------------------
+// The matryoshka forward (reference sae/quantized_matryoshka.py:97-99,217-220) needs only the BIT
+// z = sigmoid(latent) > 0.5  <=>  latent >= c (QSAE_SIG_GT_BITS) of every latent, never its value.  The fp16
+// sweep with tau = c lists every hidden unit whose approximate latent s^ is >= c - 2 eps_b.  With |s^ - s| <= eps_b:
+//   s^ - c >  eps_b   =>  s > c          bit 1, no further work
+//   s^ - c < -eps_b   =>  s < c          bit 0 (listed only because the sweep's cut is 2 eps_b wide)
+//   otherwise                            exact fp32 chain (the refine gather), bit = chain >= c
+// One wave per activation row builds the row's bit vector in LDS and writes it out once.  Rows whose list
+// overflowed (dense activations, NaN inputs) are flagged and recomputed by the exact dense kernel.
+constexpr int kBitsWaves = 4;
+constexpr int kBitsMaxUnc = 256;      // latents per row inside the uncertainty band (more -> flagged)
+constexpr int kBitsChunk = 8192;      // flagged rows per exact fallback launch
+constexpr int kBitsCap = 2048;        // list entries per row: ~2.5 % of 32768 units active plus the uncertainty band (denser
+                                      // rows also overflow the sweep's 6 records per lane and 32 latents, and are flagged)
+__host__ __device__ static inline size_t bits_lds_per_wave(int H) {
+    return static_cast<size_t>((H + 31) / 32) * 4 + 64 * kRefTileStride * 4 + kBitsMaxUnc * 4;
+}
+
+__global__ void __launch_bounds__(64 * kBitsWaves)
+resolve_bits_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, int parts,
+                    const int* __restrict__ cnt_parts, const float* __restrict__ margin, const float* __restrict__ x,
+                    const float* __restrict__ W, const float* __restrict__ bias, int B, int D, int H,
+                    uint32_t* __restrict__ zbits, int64_t words_ld, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bits_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kBitsWaves + wave;
+    if (b >= B) return;
+    const int words = (H + 31) / 32;
+    unsigned char* mybase = bits_smem + static_cast<size_t>(wave) * bits_lds_per_wave(H);
+    uint32_t* zrow = reinterpret_cast<uint32_t*>(mybase);
+    float* wt = reinterpret_cast<float*>(mybase + static_cast<size_t>(words) * 4);
+    int* hidx = reinterpret_cast<int*>(wt + 64 * kRefTileStride);
+    auto flag_row = [&]() {
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+    };
+    auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };       // one wave's LDS operations execute in order
+    typedef const __attribute__((address_space(4))) int* cint_t;
+    typedef const __attribute__((address_space(4))) float* cflt_t;
+    const int cap_part = cap / parts;
+    bool seg_overflow = false;
+    for (int p = 0; p < parts; ++p) {
+        const int np = p == 0 ? ((cint_t)cnt)[b] : ((cint_t)cnt_parts)[static_cast<size_t>(p - 1) * B + b];
+        seg_overflow |= np > cap_part;
+    }
+    if (seg_overflow) { flag_row(); return; }
+    for (int w = lane; w < words; w += 64) zrow[w] = 0u;
+    lds_handoff();
+    const float c = __uint_as_float(QSAE_SIG_GT_BITS);
+    const float half = 0.5f * ((cflt_t)margin)[b] * 1.00001f;          // eps_b with slack for the roundings below
+    const uint2* list = cand + static_cast<int64_t>(b) * cap;
+    int m = 0;                                                         // uncertain latents so far (wave-uniform)
+    bool bad = false;
+    for (int p = 0; p < parts; ++p) {
+        const int np = p == 0 ? ((cint_t)cnt)[b] : ((cint_t)cnt_parts)[static_cast<size_t>(p - 1) * B + b];
+        const uint2* seg = list + p * cap_part;
+        for (int i0 = 0; i0 < np; i0 += 64) {
+            const int i = i0 + lane;
+            bool unc = false;
+            int h = 0;
+            if (i < np) {
+                const uint2 r = seg[i];
+                const float v = __uint_as_float(r.x);
+                h = static_cast<int>(r.y);
+                const float d = v - c;
+                bad |= (v != v) || h < 0 || h >= H;
+                if (d > half) atomicOr(&zrow[h >> 5], 1u << (h & 31));
+                else unc = d >= -half;
+            }
+            const unsigned long long msk = __ballot(unc);
+            if (unc) {
+                const int pos = m + __popcll(msk & ((1ull << lane) - 1ull));
+                if (pos < kBitsMaxUnc) hidx[pos] = h;
+            }
+            m += __popcll(msk);
+        }
+    }
+    if (__any(bad) || m > kBitsMaxUnc) { flag_row(); return; }         // NaN latents / too many: the exact kernel decides
+    lds_handoff();
+    // exact fp32 chain of the uncertain latents (ascending k, seeded with the bias): the transposed block gather
+    // of refine_topk_kernel
+    typedef const __attribute__((address_space(4))) f32x4* cvec_t;
+    cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);
+    const int nblk = D / 32;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        const int h = (j < m) ? hidx[j] : hidx[j0];
+        float acc = bias ? bias[h] : 0.0f;
+        const float* rp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int jj = j0 + 8 * i + (lane >> 3);
+            jj = jj < m ? jj : j0;
+            rp[i] = W + static_cast<int64_t>(hidx[jj]) * D + 4 * (lane & 7);
+        }
+        f32x4 st[kRefSets][8];
+#pragma unroll
+        for (int q = 0; q < kRefSets; ++q)
+            if (q < nblk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * q);
+            }
+        auto consume = [&](const f32x4 (&sv)[8], int t) {
+            f32x4 xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = xrow[8 * t + q];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+            lds_handoff();
+            const float* mine = wt + lane * kRefTileStride;
+            f32x4 w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
+            lds_handoff();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc = fmaf(xv[q][0], w[q][0], acc);
+                acc = fmaf(xv[q][1], w[q][1], acc);
+                acc = fmaf(xv[q][2], w[q][2], acc);
+                acc = fmaf(xv[q][3], w[q][3], acc);
+            }
+        };
+        for (int t = 0; t < nblk; t += kRefSets) {
+#pragma unroll
+            for (int q = 0; q < kRefSets; ++q) {
+                if (t + q < nblk) {
+                    consume(st[q], t + q);
+                    if (t + q + kRefSets < nblk) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + q + kRefSets));
+                    }
+                }
+            }
+        }
+        if (j < m && sig_gt_half(acc)) atomicOr(&zrow[h >> 5], 1u << (h & 31));
+    }
+    lds_handoff();
+    uint32_t* out = zbits + static_cast<int64_t>(b) * words_ld;
+    for (int w = lane; w < words; w += 64) out[w] = zrow[w];
+}
+
+__global__ void __launch_bounds__(256)
+scatter_bit_rows_kernel(const uint32_t* __restrict__ src, const int* __restrict__ rows, int n, int words,
+                        uint32_t* __restrict__ dst, int64_t words_ld) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= static_cast<long long>(n) * words) return;
+    const int r = static_cast<int>(gid / words), w = static_cast<int>(gid % words);
+    dst[static_cast<long long>(rows[r]) * words_ld + w] = src[gid];
+}
+
+struct BitsLayout {
+    size_t tau, cnt, cnt_parts, cand, flags, xq, inv, margin, fx, fbits, total;
+};
+static BitsLayout bits_layout(int B, int D, int H) {
+    BitsLayout L;
+    size_t off = 0;
+    L.tau = off;       off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.cnt = off;       off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.cnt_parts = off; off = align_up(off + static_cast<size_t>(B) * 4 * 7, 256);
+    L.cand = off;      off = align_up(off + static_cast<size_t>(B) * kBitsCap * 8, 256);
+    L.flags = off;     off = align_up(off + (static_cast<size_t>(B) + 4) * 4, 256);
+    L.xq = off;        off = align_up(off + static_cast<size_t>(B) * D * 2, 256);
+    L.inv = off;       off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.margin = off;    off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.fx = off;        off = align_up(off + static_cast<size_t>(kBitsChunk) * D * 4, 256);
+    L.fbits = off;     off = align_up(off + static_cast<size_t>(kBitsChunk) * ((H + 31) / 32) * 4, 256);
+    L.total = off;
+    return L;
+}
+
+static bool bits_prefilter_shape_ok(int B, int D, int H) {
+    return B > 0 && xstat_supported(D, H, 0) && D % 64 == 0 && D <= kRefMaxD && H <= (1 << 20) &&
+           bits_lds_per_wave(H) * kBitsWaves <= 160 * 1024;
+}
+
+static int run_bits_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
+                              int B, int D, int H, uint32_t* zbits, int64_t words_ld, char* ws, qsae_stream_t stream,
+                              int* flagged_rows) {
+    hipStream_t s = as_stream(stream);
+    const BitsLayout L = bits_layout(B, D, H);
+    float* tau = reinterpret_cast<float*>(ws + L.tau);
+    int* cnt = reinterpret_cast<int*>(ws + L.cnt);
+    int* cnt_parts = reinterpret_cast<int*>(ws + L.cnt_parts);
+    uint2* cand = reinterpret_cast<uint2*>(ws + L.cand);
+    int* flags = reinterpret_cast<int*>(ws + L.flags);
+    _Float16* xq = reinterpret_cast<_Float16*>(ws + L.xq);
+    float* inv = reinterpret_cast<float*>(ws + L.inv);
+    float* margin = reinterpret_cast<float*>(ws + L.margin);
+    const int words = (H + 31) / 32;
+    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+    QSAE_HIP(hipMemsetAsync(cnt, 0, static_cast<size_t>(B) * 4, s));
+    QSAE_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tau), static_cast<int>(QSAE_SIG_GT_BITS), B, s));
+    if (words_ld > words)
+        QSAE_HIP(hipMemset2DAsync(zbits + words, words_ld * 4, 0, (words_ld - words) * 4, B, s));
+    hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
+    QSAE_LAUNCH_CHECK();
+    const int parts = xstat_parts(B, H, kBitsCap);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_time_sweep) {
+        QSAE_HIP(hipEventCreate(&e0));
+        QSAE_HIP(hipEventCreate(&e1));
+        QSAE_HIP(hipEventRecord(e0, s));
+    }
+    XsArgs xa{xq, Wq, bias, tau, margin, inv, cand, cnt, B, H, kBitsCap, 0, g_xstat_rot, nullptr, nullptr, 0, H, 0, 0, 0,
+              nullptr, nullptr, meta, nullptr, nullptr, parts, cnt_parts};
+    int rc = launch_xstat(D, xa, s, 0);
+    if (g_time_sweep) {
+        QSAE_HIP(hipEventRecord(e1, s));
+        g_sweep_events.emplace_back(e0, e1);
+    }
+    if (rc != QSAE_OK) return rc;
+    {
+        const size_t lds = bits_lds_per_wave(H) * kBitsWaves;
+        static bool configured = false;
+        if (!configured) {
+            QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_bits_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = true;
+        }
+        hipLaunchKernelGGL(resolve_bits_kernel, dim3((B + kBitsWaves - 1) / kBitsWaves), dim3(64 * kBitsWaves), lds, s,
+                           cand, cnt, kBitsCap, parts, cnt_parts, margin, x, W, bias, B, D, H, zbits, words_ld, flags);
+        QSAE_LAUNCH_CHECK();
+    }
+    // flagged rows: exact dense kernel on the gathered rows (the count comes back through a pinned word)
+    static thread_local int* pinned = nullptr;
+    static thread_local hipEvent_t copied = nullptr;
+    if (!pinned) QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
+    if (!copied) QSAE_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+    *pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipEventRecord(copied, s));
+    QSAE_HIP(hipEventSynchronize(copied));
+    const int nflag = *pinned;
+    g_last_flagged = nflag;
+    if (flagged_rows) *flagged_rows = nflag;
+    float* fx = reinterpret_cast<float*>(ws + L.fx);
+    uint32_t* fbits = reinterpret_cast<uint32_t*>(ws + L.fbits);
+    for (int f0 = 0; f0 < nflag; f0 += kBitsChunk) {
+        const int n = (nflag - f0) < kBitsChunk ? (nflag - f0) : kBitsChunk;
+        const int* rows = flags + 1 + f0;
+        const long long tot = static_cast<long long>(n) * D;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows, n,
+                           D, fx);
+        QSAE_LAUNCH_CHECK();
+        rc = qsae_encode_bits(fx, W, bias, n, D, H, fbits, words, stream);
+        if (rc != QSAE_OK) return rc;
+        const long long tw = static_cast<long long>(n) * words;
+        hipLaunchKernelGGL(scatter_bit_rows_kernel, dim3(static_cast<unsigned>((tw + 255) / 256)), dim3(256), 0, s, fbits,
+                           rows, n, words, zbits, words_ld);
+        QSAE_LAUNCH_CHECK();
+    }
+    return QSAE_OK;
+}
+
 }  // namespace qsae
 
 using namespace qsae;
@@ -1200,4 +1459,26 @@ extern "C" int qsae_encode_topk_prefilter(const float* x, const float* W, const 
     if (dense) QSAE_CHECK_ARG(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense), "dense latent alignment / ld");
     return run_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, k, idx, val,
                          static_cast<char*>(workspace), stream, dense, dense_ld);
+}
+
+extern "C" size_t qsae_encode_bits_prefilter_workspace_bytes(int B, int D, int H) {
+    if (!bits_prefilter_shape_ok(B, D, H)) return 0;
+    return bits_layout(B, D, H).total;
+}
+
+extern "C" int qsae_encode_bits_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                                          const float* meta, int B, int D, int H, uint32_t* zbits, int64_t words_ld,
+                                          void* workspace, size_t workspace_bytes, int* flagged_rows,
+                                          qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (flagged_rows) *flagged_rows = 0;
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(x && W && Wq && meta && zbits, "null pointer");
+    QSAE_CHECK_ARG(words_ld >= (H + 31) / 32, "words_ld < ceil(H/32)");
+    QSAE_CHECK_SUPPORTED(bits_prefilter_shape_ok(B, D, H), "shape not covered by the fp16 candidate sweep (D in {128,256,512}, H % 64 == 0)");
+    QSAE_CHECK_ARG(aligned16(x) && aligned16(W) && aligned16(Wq), "x, W and Wq must be 16-byte aligned");
+    QSAE_CHECK_ARG(workspace && workspace_bytes >= bits_layout(B, D, H).total, "workspace too small");
+    QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
+    return run_bits_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld,
+                              static_cast<char*>(workspace), stream, flagged_rows);
 }

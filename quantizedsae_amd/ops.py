@@ -128,6 +128,31 @@ def encode_bits(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) 
     return z
 
 
+def encode_bits_prefilter_supported(B: int, D: int, H: int) -> bool:
+    return B > 0 and int(_lib.load().qsae_encode_bits_prefilter_workspace_bytes(B, D, H)) > 0
+
+
+def encode_bits_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                          meta: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """z bits identical to encode_bits, from the fp16 candidate sweep + exact re-evaluation of the latents near the
+    cutoff.  Returns (zbits int32 [B, ceil(H/32)], rows that went through the exact dense kernel)."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    lib = _lib.load()
+    need = int(lib.qsae_encode_bits_prefilter_workspace_bytes(B, D, H))
+    if need == 0:
+        raise ValueError("shape not supported by the fp16 candidate sweep")
+    ws = _workspace(x.device, need)
+    words = (H + 31) // 32
+    z = torch.empty((B, words), dtype=torch.int32, device=x.device)
+    flagged = C.c_int(0)
+    check(lib.qsae_encode_bits_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, _p(z), words, _p(ws),
+                                         ws.numel(), C.byref(flagged), _stream()))
+    return z, int(flagged.value)
+
+
 def topk_rows(latent: torch.Tensor, k: int, zero_rest: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """In-place on `latent` when zero_rest.  Returns (idx int32 [B,k], val f32 [B,k])."""
     _dev(latent, "latent", torch.float32)
@@ -360,6 +385,34 @@ def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, s
     check(_lib.load().qsae_decode_matryoshka(_p(zbits), zbits.stride(0) if B else (H + 31) // 32, B, H, D, n_bits,
                                              sp, _p(codes), _p(scale), _p(b), 1 if allow_bias else 0, _p(levels),
                                              _p(counts), _stream()))
+    return levels, counts
+
+
+def pack_matryoshka_rows(w: torch.Tensor, wm: torch.Tensor) -> torch.Tensor:
+    """-> codes_rows int32 [H, ceil(D/16)]: the dictionary in hidden-major order for decode_matryoshka_sparse."""
+    w, wm = _f32c(w, "w"), _f32c(wm, "wm")
+    H, D = w.shape
+    codes = torch.empty((H, (D + 15) // 16), dtype=torch.int32, device=w.device)
+    check(_lib.load().qsae_pack_matryoshka_rows(_p(w), _p(wm), H, D, _p(codes), _stream()))
+    return codes
+
+
+def decode_matryoshka_sparse_supported(D: int) -> bool:
+    return D in (64, 128, 256, 512, 1024)
+
+
+def decode_matryoshka_sparse(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes_rows, scale, bias,
+                             allow_bias: bool, sizes=None):
+    """decode_matryoshka on the active units only (same outputs)."""
+    _dev(zbits, "zbits", torch.int32)
+    B = zbits.shape[0]
+    levels = torch.empty((n_bits, B, D), dtype=torch.float32, device=zbits.device)
+    counts = torch.zeros((n_bits,), dtype=torch.int64, device=zbits.device)
+    b = _f32c(bias, "bias") if bias is not None else None
+    keep, sp = _sizes_arg(sizes, n_bits)
+    check(_lib.load().qsae_decode_matryoshka_sparse(_p(zbits), zbits.stride(0) if B else (H + 31) // 32, B, H, D,
+                                                    n_bits, sp, _p(codes_rows), _p(scale), _p(b),
+                                                    1 if allow_bias else 0, _p(levels), _p(counts), _stream()))
     return levels, counts
 
 

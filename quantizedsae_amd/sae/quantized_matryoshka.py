@@ -100,16 +100,24 @@ class QuantizedMatryoshkaDecoder(nn.Module):
                 st.update(sizes=self.padded_sizes, H=Hp, index=index)
             codes, scale = ops.pack_matryoshka(w, wm, self.n_bits, self.abs_range, st["sizes"])
             st.update(codes=codes, scale=scale)
+            if ops.decode_matryoshka_sparse_supported(self.out_features):
+                st["codes_rows"] = ops.pack_matryoshka_rows(w, wm)      # hidden-major copy for the sparse walk
             return st
         return self._cache.get((self.weight, self.weight_mirror), build)
 
     # -- decode ---------------------------------------------------------------------------------
-    def decode_bits(self, zbits: torch.Tensor) -> Tuple[list, list]:
-        """zbits: int32-packed [B, H_padded/32] in the packed (padded) hidden order."""
+    def decode_bits(self, zbits: torch.Tensor, sparse: bool = False) -> Tuple[list, list]:
+        """zbits: int32-packed [B, H_padded/32] in the packed (padded) hidden order.  ``sparse``: walk the active
+        units only (same outputs; for rows with few active units)."""
         st = self.packed()
         B = zbits.shape[0]
-        levels, counts = ops.decode_matryoshka(zbits, st["H"], self.out_features, self.n_bits, st["codes"],
-                                               st["scale"], self.bias.detach(), self.allow_bias, st["sizes"])
+        if sparse and "codes_rows" in st:
+            levels, counts = ops.decode_matryoshka_sparse(zbits, st["H"], self.out_features, self.n_bits,
+                                                          st["codes_rows"], st["scale"], self.bias.detach(),
+                                                          self.allow_bias, st["sizes"])
+        else:
+            levels, counts = ops.decode_matryoshka(zbits, st["H"], self.out_features, self.n_bits, st["codes"],
+                                                   st["scale"], self.bias.detach(), self.allow_bias, st["sizes"])
         groups = (counts.to(torch.float64) / max(B, 1)).to(torch.float32)
         return [groups[i] for i in range(self.n_bits)], [levels[i] for i in range(self.n_bits)]
 
@@ -168,12 +176,57 @@ class QuantizedMatryoshkaSAE(SparseAutoencoder):
         st = self._enc_cache.get((lin.weight, lin.bias), build)
         return st["W"], st["b"]
 
-    def activation_bits(self, x) -> torch.Tensor:
+    #: "auto" | "dense" | "prefilter".  dense: every latent from the exact-fp32 MFMA contraction, dense decoder.
+    #: prefilter: the z bits from the fp16 candidate sweep (latents near the sigmoid cutoff re-evaluated exactly)
+    #: and the decoder walks the active units only -- bit-identical outputs, pays off when few units fire per row.
+    #: auto: prefilter for large batches until a batch shows dense activations (more than 1/8 of its rows
+    #: overflow their candidate lists, i.e. more than ~2.5 % of the units fire), then dense for this model.
+    bits_path = "auto"
+    _PREFILTER_MIN_ROWS = 2048
+
+    def resolved_bits_path(self, batch_rows: int) -> str:
+        path = self.bits_path
+        if path not in ("auto", "dense", "prefilter"):
+            raise ValueError(f"bits_path must be 'auto', 'dense' or 'prefilter', got {path!r}")
+        W, _ = self._encoder_params()
+        ok = ops.encode_bits_prefilter_supported(batch_rows, self.input_dim, W.shape[0])
+        if path == "auto":
+            big = batch_rows >= self._PREFILTER_MIN_ROWS and W.shape[0] >= 8192
+            path = "prefilter" if (big and ok and not getattr(self, "_dense_regime", False)) else "dense"
+        if path == "prefilter" and not ok:
+            path = "dense"
+        return path
+
+    def _prefilter_weights(self):
+        W, b = self._encoder_params()
+        if not hasattr(self, "_pref_cache"):
+            self._pref_cache = PackedCache()
+        lin = self.encoder.linear
+
+        def build():
+            self._dense_regime = False                     # new weights: probe the activation density again
+            Wq, meta = ops.prefilter_pack_w(W, b)
+            return {"Wq": Wq, "meta": meta}
+        return self._pref_cache.get((lin.weight, lin.bias), build)
+
+    def activation_bits(self, x, path: str = None) -> torch.Tensor:
         """int32-packed z = (sigmoid(encoder pre-activation) > 0.5) in packed hidden order."""
         with torch.no_grad():
             W, b = self._encoder_params()
-            return ops.encode_bits(require_device_input(x, "x"), W, b)
+            x = require_device_input(x, "x")
+            if (path or self.resolved_bits_path(x.shape[0])) == "prefilter":
+                pw = self._prefilter_weights()
+                z, flagged = ops.encode_bits_prefilter(x.float(), W, b, pw["Wq"], pw["meta"])
+                self.last_flagged_rows = flagged
+                if flagged * 8 > x.shape[0]:
+                    self._dense_regime = True
+                return z
+            return ops.encode_bits(x, W, b)
 
     def forward(self, x):
         with torch.no_grad():
-            return self.decoder.decode_bits(self.activation_bits(x))
+            x = require_device_input(x, "x")
+            path = self.resolved_bits_path(x.shape[0])
+            z = self.activation_bits(x, path)
+            sparse = path == "prefilter" and not getattr(self, "_dense_regime", False)
+            return self.decoder.decode_bits(z, sparse=sparse)

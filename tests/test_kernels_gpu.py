@@ -284,6 +284,80 @@ def test_matryoshka_pack_and_decode(B, D, H, n_bits, abs_range):
     assert rel_err(host(levels_nb[-1]), want_nb[-1]) < 1e-5
 
 
+@pytest.mark.parametrize("B,D,H,shift", [(2500, 512, 8192, -2.5), (4096, 256, 4096, -2.0), (700, 128, 2048, -1.5),
+                                         (2048, 512, 32768, -2.5), (1024, 512, 8192, 0.0)])
+def test_encode_bits_prefilter_matches_exact(B, D, H, shift):
+    """z bits from the fp16 candidate sweep + exact re-evaluation near the cutoff == the exact dense kernel's bits
+    (which the oracle pins, test_encode_bits); shift = encoder bias in standard deviations of the latent
+    (0: half of the units fire, every row overflows its list and takes the exact fallback)."""
+    ops = _ops()
+    x = S.activations(81, B, D)
+    x[3] *= 40.0                                           # rows of very different norm: per-row scales and margins
+    x[5] *= 1e-3
+    W = S.xavier_uniform(81, H, D, stream=1)
+    sigma = float(np.sqrt(D) * np.sqrt(6.0 / (D + H)) / np.sqrt(3.0))
+    bias = (S.normal(81, (H,), stream=3, std=0.05 * sigma) + shift * sigma).astype(np.float32)
+    # latents exactly at and around the cutoff: unit h0 has zero weights, its latent is its bias
+    gt, _ = oracle.sigmoid_cutoffs()
+    W[10] = 0.0; bias[10] = gt
+    W[11] = 0.0; bias[11] = np.nextafter(gt, np.float32(-1))
+    W[12] = 0.0; bias[12] = 0.0
+    xd, Wd, bd = dev(x), dev(W), dev(bias)
+    want = ops.encode_bits(xd, Wd, bd)
+    Wq, meta = ops.prefilter_pack_w(Wd, bd)
+    got, flagged = ops.encode_bits_prefilter(xd, Wd, bd, Wq, meta)
+    assert torch.equal(got, want)
+    if shift == 0.0:
+        assert flagged == B
+    elif shift <= -2.0:
+        assert flagged < B // 8                            # (-1.5: ~7 % of the units fire, a quarter of the rows overflow)
+    bits = np.unpackbits(host(got).view(np.uint8), axis=1, bitorder="little")
+    assert bits[:, 10].all() and not bits[:, 11].any() and not bits[:, 12].any()
+    # small oracle cross-check on a few rows
+    lat = oracle.encode(x[:8], W, bias, oracle.ACT_NONE)
+    assert np.array_equal(bits[:8, :H], (lat >= gt).astype(np.uint8))
+
+
+def test_encode_bits_prefilter_nonfinite_rows():
+    ops = _ops()
+    B, D, H = 1024, 512, 4096
+    x = S.activations(82, B, D)
+    x[7, 3] = np.nan
+    x[9, 100] = np.inf
+    W = S.xavier_uniform(82, H, D, stream=1)
+    bias = np.full((H,), -1.25, np.float32)                # ~ -2.6 standard deviations of the latent
+    xd, Wd, bd = dev(x), dev(W), dev(bias)
+    Wq, meta = ops.prefilter_pack_w(Wd, bd)
+    got, flagged = ops.encode_bits_prefilter(xd, Wd, bd, Wq, meta)
+    assert torch.equal(got, ops.encode_bits(xd, Wd, bd))
+    assert 2 <= flagged < 64
+
+
+@pytest.mark.parametrize("B,D,H,n_bits,density", [(300, 512, 4096, 4, 0.01), (1000, 512, 32768, 4, 0.006),
+                                                   (257, 64, 1024, 4, 0.05), (130, 256, 2048, 3, 0.5),
+                                                   (64, 1024, 4096, 8, 0.02), (33, 128, 512, 1, 0.1)])
+def test_matryoshka_sparse_decode_matches_dense(B, D, H, n_bits, density):
+    """the walk over the active units gives the dense kernel's levels bit for bit (same chain, zero terms skipped)"""
+    ops = _ops()
+    sd = S.matryoshka_sae_params(90, D, H, bias_std=0.3)
+    w, wm, bias = dev(sd["decoder.weight"]), dev(sd["decoder.weight_mirror"]), dev(sd["decoder.bias"])
+    sizes = [(s + 31) // 32 * 32 for s in ops.matryoshka_sizes(H, n_bits)]
+    sizes[-1] = H - sum(sizes[:-1])
+    assert sizes[-1] > 0 and sizes[-1] % 32 == 0
+    codes, scale = ops.pack_matryoshka(w, wm, n_bits, 4.0, sizes)
+    rows = ops.pack_matryoshka_rows(w, wm)
+    zb = (S.uniform(91, (B, H), 0, 1, stream=3) < density).astype(np.uint8)
+    zb[1] = 0                                              # an empty row
+    zb[2] = 1                                              # every unit active
+    zb[3] = 0; zb[3, H - 1] = 1                            # only the last unit
+    zwords = dev(np.packbits(zb, axis=1, bitorder="little").view(np.int32))
+    for allow_bias in (True, False):
+        want, want_counts = ops.decode_matryoshka(zwords, H, D, n_bits, codes, scale, bias, allow_bias, sizes)
+        got, counts = ops.decode_matryoshka_sparse(zwords, H, D, n_bits, rows, scale, bias, allow_bias, sizes)
+        assert torch.equal(got, want)
+        assert torch.equal(counts, want_counts)
+
+
 def test_error_codes():
     from quantizedsae_amd import _lib
     ops = _ops()

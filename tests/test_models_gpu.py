@@ -136,6 +136,33 @@ def test_ternary_sae(name):
     assert np.max(np.abs(host(h) - fx["latent"])) < 4e-6
 
 
+@pytest.mark.parametrize("B,shift", [(4096, -2.5), (2304, -2.0), (2048, 0.0)])
+def test_matryoshka_prefilter_path_matches_dense_path(B, shift):
+    """QuantizedMatryoshkaSAE.forward through the candidate sweep + sparse walk == the exact dense kernels, bit for
+    bit; with half of the units firing (shift 0) the model notices and stays on the dense kernels."""
+    D, H, n_bits = 512, 32768, 4
+    sd = S.matryoshka_sae_params(95, D, H, enc_bias_sigmas=shift, bias_std=0.2)
+    model = load(QuantizedMatryoshkaSAE(D, H, 32, abs_range=4, n_bits=n_bits), sd)
+    x = dev(S.activations(96, B, D))
+    model.bits_path = "dense"
+    g0, l0 = model(x)
+    model.bits_path = "auto"
+    assert model.resolved_bits_path(B) == "prefilter"
+    g1, l1 = model(x)
+    for i in range(n_bits):
+        assert torch.equal(l0[i], l1[i]), i
+        assert float(g0[i]) == float(g1[i])
+    if shift == 0.0:
+        assert model.last_flagged_rows == B and model.resolved_bits_path(B) == "dense"
+    else:
+        assert model.last_flagged_rows < B // 8 and model.resolved_bits_path(B) == "prefilter"
+        # a CPU cross-check of the first rows against the oracle
+        want = oracle.matryoshka_forward(host(x[:16]), sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                         sd["decoder.weight_mirror"], sd["decoder.bias"], n_bits=n_bits, abs_range=4)
+        for i in range(n_bits):
+            assert rel_err(host(l1[i][:16]), want["reconstruction_levels"][i]) < RECON_TOL, i
+
+
 @pytest.mark.parametrize("name", ["matryoshka_small", "matryoshka_edge", "matryoshka_mid", "matryoshka_full"])
 def test_matryoshka_sae(name):
     fx = Fixture(name)
