@@ -169,26 +169,30 @@ struct EpiLevels {
     __device__ __forceinline__ void finish(const Args&, f32x16 (&)[MT][NT], const TileCtx&) {}
 };
 
-// l0_counts[level] += popcount of the level's z bits (level boundaries multiples of 32)
+// l0_counts[level] += popcount of the level's z bits (level boundaries multiples of 32).  A workgroup walks whole
+// rows (no division per word), a lane keeps its level's running count while its word index stays in that level.
 __global__ void __launch_bounds__(256)
 count_bits_kernel(const uint32_t* __restrict__ zbits, int64_t words_ld, int B, int words, LevelTable lv,
                   unsigned long long* __restrict__ counts) {
     unsigned long long local[kMaxLevels] = {0};
-    const long long total = static_cast<long long>(B) * words;
-    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
-         i += static_cast<long long>(gridDim.x) * blockDim.x) {
-        const long long b = i / words;
-        const int wi = static_cast<int>(i % words);
-        const uint32_t v = zbits[b * words_ld + wi];
+    for (int wi = threadIdx.x; wi < words; wi += 256) {
         int level = 0;
         while (level < lv.n - 1 && wi * 32 >= lv.end[level]) ++level;
+        unsigned long long c = 0;
+        for (int b = blockIdx.x; b < B; b += gridDim.x) c += __popc(zbits[static_cast<int64_t>(b) * words_ld + wi]);
 #pragma unroll
-        for (int l = 0; l < kMaxLevels; ++l) local[l] += (l == level) ? __popc(v) : 0;
+        for (int l = 0; l < kMaxLevels; ++l) local[l] += (l == level) ? c : 0ull;
     }
+    __shared__ unsigned long long part[4][kMaxLevels];
     for (int l = 0; l < lv.n; ++l) {
         unsigned long long v = local[l];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counts[l], v);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][l] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < lv.n) {
+        const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (v) atomicAdd(&counts[threadIdx.x], v);
     }
 }
 
@@ -249,11 +253,14 @@ decode_matryoshka_sparse_kernel(const uint32_t* __restrict__ zbits, int64_t word
 #pragma unroll
         for (int f = 0; f < FPL; ++f) out[f] = acc[f] + bcol[f];
     };
+    // the dense kernel's term is fmaf(scale_j, S, acc) with S in {-2, 0, 2}; 2 * scale_j is exact, so
+    // fmaf(2 * scale_j, S / 2, acc) rounds the same real number
     auto add_unit = [&](int j, uint32_t cw, float a) {
         const int w = static_cast<int>(cw >> wshift);
+        const float t = 2.0f * a;
 #pragma unroll
         for (int f = 0; f < FPL; ++f)
-            acc[f] = fmaf(a, static_cast<float>(2 * sbfe_i32(w, 2 * f, 2)), acc[f]);
+            acc[f] = fmaf(t, static_cast<float>(sbfe_i32(w, 2 * f, 2)), acc[f]);
     };
     const int words = H / 32;
     const uint32_t* zrow = zbits + static_cast<int64_t>(b) * words_ld;
@@ -447,9 +454,7 @@ extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, i
     if (l0_counts) {
         QSAE_HIP(hipMemsetAsync(l0_counts, 0, sizeof(unsigned long long) * n_bits, s));
         const int words = H / 32;
-        long long total = static_cast<long long>(B) * words;
-        long long blocks = (total + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        long long blocks = B < 2048 ? B : 2048;
         hipLaunchKernelGGL(count_bits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, zbits, words_ld, B,
                            words, lv, l0_counts);
         QSAE_LAUNCH_CHECK();
@@ -487,8 +492,7 @@ extern "C" int qsae_decode_matryoshka_sparse(const uint32_t* zbits, int64_t word
     if (l0_counts) {
         QSAE_HIP(hipMemsetAsync(l0_counts, 0, sizeof(unsigned long long) * n_bits, s));
         const int words = H / 32;
-        long long blocks = (static_cast<long long>(B) * words + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        long long blocks = B < 2048 ? B : 2048;
         hipLaunchKernelGGL(count_bits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, zbits, words_ld, B,
                            words, lv, l0_counts);
         QSAE_LAUNCH_CHECK();

@@ -1016,6 +1016,7 @@ constexpr int kBitsMaxUnc = 256;      // latents per row inside the uncertainty 
 constexpr int kBitsChunk = 8192;      // flagged rows per exact fallback launch
 constexpr int kBitsCap = 2048;        // list entries per row: ~2.5 % of 32768 units active plus the uncertainty band (denser
                                       // rows also overflow the sweep's 6 records per lane and 32 latents, and are flagged)
+constexpr int kBitsSets = 3;          // W blocks in flight per wave (of D/32): 8 x 16-byte loads per lane each
 __host__ __device__ static inline size_t bits_lds_per_wave(int H) {
     return static_cast<size_t>((H + 31) / 32) * 4 + 64 * kRefTileStride * 4 + kBitsMaxUnc * 4;
 }
@@ -1061,31 +1062,40 @@ resolve_bits_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt,
     for (int p = 0; p < parts; ++p) {
         const int np = p == 0 ? ((cint_t)cnt)[b] : ((cint_t)cnt_parts)[static_cast<size_t>(p - 1) * B + b];
         const uint2* seg = list + p * cap_part;
-        for (int i0 = 0; i0 < np; i0 += 64) {
-            const int i = i0 + lane;
-            bool unc = false;
-            int h = 0;
-            if (i < np) {
-                const uint2 r = seg[i];
-                const float v = __uint_as_float(r.x);
-                h = static_cast<int>(r.y);
-                const float d = v - c;
-                bad |= (v != v) || h < 0 || h >= H;
-                if (d > half) atomicOr(&zrow[h >> 5], 1u << (h & 31));
-                else unc = d >= -half;
+        for (int i0 = 0; i0 < np; i0 += 256) {
+            uint2 r[4];                                                // four list slots per lane in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u + lane;
+                r[u] = i < np ? seg[i] : uint2{0u, 0u};
             }
-            const unsigned long long msk = __ballot(unc);
-            if (unc) {
-                const int pos = m + __popcll(msk & ((1ull << lane) - 1ull));
-                if (pos < kBitsMaxUnc) hidx[pos] = h;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + 64 * u >= np) break;                          // wave-uniform
+                const int i = i0 + 64 * u + lane;
+                bool unc = false;
+                const int h = static_cast<int>(r[u].y);
+                if (i < np) {
+                    const float v = __uint_as_float(r[u].x);
+                    const float d = v - c;
+                    bad |= (v != v) || h < 0 || h >= H;
+                    if (d > half) atomicOr(&zrow[h >> 5], 1u << (h & 31));
+                    else unc = d >= -half;
+                }
+                const unsigned long long msk = __ballot(unc);
+                if (unc) {
+                    const int pos = m + __popcll(msk & ((1ull << lane) - 1ull));
+                    if (pos < kBitsMaxUnc) hidx[pos] = h;
+                }
+                m += __popcll(msk);
             }
-            m += __popcll(msk);
         }
     }
     if (__any(bad) || m > kBitsMaxUnc) { flag_row(); return; }         // NaN latents / too many: the exact kernel decides
     lds_handoff();
     // exact fp32 chain of the uncertain latents (ascending k, seeded with the bias): the transposed block gather
-    // of refine_topk_kernel
+    // of refine_topk_kernel.  ~30 latents x 2 KiB of W per row: this gather (3.9 GB per 65536 rows at the headline
+    // shape) is what the kernel's time is.
     typedef const __attribute__((address_space(4))) f32x4* cvec_t;
     cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);
     const int nblk = D / 32;
@@ -1094,18 +1104,21 @@ resolve_bits_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt,
         const int h = (j < m) ? hidx[j] : hidx[j0];
         float acc = bias ? bias[h] : 0.0f;
         const float* rp[8];
+        bool live[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int jj = j0 + 8 * i + (lane >> 3);
-            jj = jj < m ? jj : j0;
+            live[i] = jj < m;                                          // rows past the list are not fetched at all
+            jj = live[i] ? jj : j0;
             rp[i] = W + static_cast<int64_t>(hidx[jj]) * D + 4 * (lane & 7);
         }
-        f32x4 st[kRefSets][8];
+        f32x4 st[kBitsSets][8];
 #pragma unroll
-        for (int q = 0; q < kRefSets; ++q)
+        for (int q = 0; q < kBitsSets; ++q)
             if (q < nblk) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * q);
+                for (int i = 0; i < 8; ++i)
+                    if (live[i]) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * q);
             }
         auto consume = [&](const f32x4 (&sv)[8], int t) {
             f32x4 xv[8];
@@ -1128,15 +1141,15 @@ resolve_bits_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt,
                 acc = fmaf(xv[q][3], w[q][3], acc);
             }
         };
-        for (int t = 0; t < nblk; t += kRefSets) {
+        for (int t = 0; t < nblk; t += kBitsSets) {
 #pragma unroll
-            for (int q = 0; q < kRefSets; ++q) {
+            for (int q = 0; q < kBitsSets; ++q) {
                 if (t + q < nblk) {
                     consume(st[q], t + q);
-                    if (t + q + kRefSets < nblk) {
+                    if (t + q + kBitsSets < nblk) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + q + kRefSets));
+                            if (live[i]) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + q + kBitsSets));
                     }
                 }
             }
