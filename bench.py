@@ -135,15 +135,25 @@ def secondary_configs(device, x):
         run("config 3: TernarySparseAutoencoder(512,32768), dense latent + reconstruction", m, lambda mm, xx: mm(xx), B,
             4.0 * D * H)
         m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)
-        m.encoder[0].bias.fill_(-0.44)
+        m.encoder[0].bias.fill_(-0.44)                     # -2.5 standard deviations of the latent: ~200 of 32768 units fire per row
         m.decoder.weight.uniform_(-1, 1)
         m.decoder.weight_mirror.uniform_(-1, 1)
-        run("config 4: QuantizedMatryoshkaSAE(512,32768,n_bits=4), 4 reconstruction levels", m, lambda mm, xx: mm(xx), B,
-            4.0 * D * H)
+        run("config 4: QuantizedMatryoshkaSAE(512,32768,n_bits=4), 4 reconstruction levels, encoder bias -2.5 sigma "
+            "(~200 active units per row): z bits from the fp16 candidate sweep + exact re-evaluation at the cutoff, "
+            "decoder walks the active units; bit-identical to the dense kernels", m, lambda mm, xx: mm(xx), B, 4.0 * D * H)
+        m.bits_path = "dense"
+        run("config 4, same model through the exact dense kernels only (fp32 MFMA encoder + dense decoder)", m,
+            lambda mm, xx: mm(xx), B, 4.0 * D * H)
+        m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)
+        m.decoder.weight.uniform_(-1, 1)
+        m.decoder.weight_mirror.uniform_(-1, 1)
+        run("config 4 at random init (encoder bias 0: half of the units fire, dense kernels)", m, lambda mm, xx: mm(xx),
+            B, 4.0 * D * H)
         run("baseline_sae: BaselineSparseAutoencoder(512,32768) top-32", BaselineSparseAutoencoder(D, H),
             lambda mm, xx: mm(xx), B, 2.0 * D * H + 2.0 * 32 * D)
         m = ResidualQuantizedSAE(D, H, top_k=32, abs_range=1.5, n_bits=4)
-        run("rq_sae: ResidualQuantizedSAE(512,32768,n_bits=4)", m, lambda mm, xx: mm(xx), min(B, 32768), 4.0 * D * H)
+        run("rq_sae: ResidualQuantizedSAE(512,32768,n_bits=4), random init (dense activations)", m, lambda mm, xx: mm(xx),
+            min(B, 32768), 4.0 * D * H)
         m = BinarySAE(D, H, gamma=GAMMA, n_bits=N_BITS)
         m.decoder.weight.copy_(torch.where(torch.rand_like(m.decoder.weight) > 0.5, 30.0, -30.0))
         run("config 2, compact outputs (idx, val, reconstruction; no dense latent)", m,

@@ -191,7 +191,7 @@ class QuantizedMatryoshkaSAE(SparseAutoencoder):
         W, _ = self._encoder_params()
         ok = ops.encode_bits_prefilter_supported(batch_rows, self.input_dim, W.shape[0])
         if path == "auto":
-            big = batch_rows >= self._PREFILTER_MIN_ROWS and W.shape[0] >= 8192
+            big = batch_rows >= self._PREFILTER_MIN_ROWS and W.shape[0] >= 2048
             path = "prefilter" if (big and ok and not getattr(self, "_dense_regime", False)) else "dense"
         if path == "prefilter" and not ok:
             path = "dense"
