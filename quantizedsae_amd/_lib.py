@@ -10,7 +10,10 @@ from pathlib import Path
 from typing import Optional
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libqsae_hip.so"
+import os
+
+# QSAE_HIP_LIB: another build of the same library (same-box A/B timing of two builds); default: the in-tree one
+LIB_PATH = Path(os.environ["QSAE_HIP_LIB"]) if os.environ.get("QSAE_HIP_LIB") else _PKG / "lib" / "libqsae_hip.so"
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4

@@ -31,7 +31,8 @@ __device__ __forceinline__ void pref_row_params(float mx, float ss, int D, float
         eps = c1 * nrm * wn                                         // relative to sum_k |x_k||w_k| <= ||x|| ||w||
               + (D + 8.0f) * u * bmax                               // every chain step (and the final fma) also rounds at the bias' magnitude
               + 8.0f * u * nrm * wn
-              + 6.0e-8f * sd * (wn / sx + nrm / sw);                // fp16 subnormal flushing of tiny elements
+              + 6.0e-8f * sd * (wn / sx + nrm / sw)                 // fp16 subnormal flushing of tiny elements
+              + 4.0e-6f * (nrm * wn + bmax);                        // candidate records carry the latent truncated by < 2^-18
         eps *= 1.0001f;
         inv = (1.0f / sx) * (1.0f / sw);                            // powers of two: exact
     }

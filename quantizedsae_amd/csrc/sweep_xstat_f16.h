@@ -36,7 +36,9 @@ constexpr int kXsWaves = 8;
 constexpr int kXsRows = 32 * kXsWaves;     // activation rows per workgroup
 constexpr int kXsHT = 64;                  // hidden rows per stage (two MFMA row tiles)
 constexpr int kXsStages = 2;
-constexpr int kXsSlots = 6;                // candidate records per lane between flushes (+1 overflow slot)
+constexpr int kXsRingSlots = 14;           // 4-byte record slots per lane ([slot][lane] image, 256 B per slot and wave)
+constexpr int kXsClamp = 10;               // a lane's write position is clamped to this slot after every 4 filtered values
+constexpr int kXsSlots = kXsClamp - 1;     // records a lane can hold between flushes (position kXsClamp = "overflowed")
 
 struct XsArgs {
     const _Float16* __restrict__ xq;      // [B][D] scaled fp16 activations
@@ -77,7 +79,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
     constexpr int BIAS_BYTES = kXsHT * 4;                    // one stage's bias; three copies in rotation
     constexpr int BIAS_BASE = kXsStages * STAGE_BYTES;
     constexpr int RING_BASE = BIAS_BASE + 3 * BIAS_BYTES;
-    constexpr int RING_WAVE = (kXsSlots + 1) * 512;          // [slot][lane] records of 8 bytes
+    constexpr int RING_WAVE = kXsRingSlots * 256;            // [slot][lane] records of 4 bytes
+    static_assert(kXsClamp + 4 <= kXsRingSlots, "four unclamped writes past the clamp position must stay inside the ring");
     constexpr int LDS_END = RING_BASE + kXsWaves * RING_WAVE;
     static_assert(IPW >= 1 && (kXsHT * CPR) % (64 * kXsWaves) == 0, "stage must split evenly over the waves");
     static_assert(LDS_END <= 160 * 1024, "LDS budget");
@@ -156,7 +159,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
         voff[i] = static_cast<unsigned>((r * CPR + (pos ^ (r & SW))) * 16);
     }
     char* bias_lds = xs_smem + BIAS_BASE;
-    char* my_ring = xs_smem + RING_BASE + wave * RING_WAVE + lane * 8;     // this lane's slot 0
+    char* my_ring = xs_smem + RING_BASE + wave * RING_WAVE + lane * 4;     // this lane's slot 0
     if (!a.bias && tid < 3 * kXsHT) reinterpret_cast<float*>(bias_lds)[tid] = 0.f;   // no bias: the copies stay zero
     // Small batches have fewer 256-row panels than the chip has CUs: the hidden range is then split over
     // gridDim.y parts, each with its own segment of every row's candidate list and its own counter.
@@ -240,14 +243,21 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // overflowed its slots pushes the row's length past cap: the row takes the exact fallback like any
     // other overflowing row.
     f32x16 acc[MT];
-    int nrec = 0;                                            // records in this lane's slots
     int count = (row_ok && part == 0 && ps == 0) ? a.cnt[crow] : 0;   // this part's segment length (equal in both lanes)
     uint2* list = a.cand + static_cast<int64_t>(crow) * a.cap + part * cap_part;
     typedef __attribute__((address_space(3))) char* lds_char_t;
     const unsigned ring_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char_t)my_ring));   // LDS byte address
-    auto flush = [&]() {
-        if (__builtin_amdgcn_ballot_w64(nrec > 0) != 0ull) {
+    const unsigned ring_limit = ring_addr + kXsClamp * 256u;
+    unsigned waddr = ring_addr;                              // next free record slot of this lane
+    const int lane_h = a.hidden_offset + 4 * lane_half;
+    // Records are 4 bytes: the approximate latent with its low 5 mantissa bits replaced by (row tile << 4 | accumulator
+    // register), i.e. which of the lane's 32 values of a block it is; the block itself is known at flush time (tile 0
+    // records belong to block blk0, tile 1 records to blk1).  The truncation (< 2^-18 relative, towards zero) is part
+    // of the error budget (prefilter_common.h).
+    auto flush = [&](int blk0, int blk1) {
+        if (__builtin_amdgcn_ballot_w64(waddr != ring_addr) != 0ull) {
             asm volatile("" ::: "memory");
+            const int nrec = static_cast<int>((waddr - ring_addr) >> 8);
             // partner lane's count: v_permlane32_swap exchanges the half-waves in one VALU instruction
             const auto sw = __builtin_amdgcn_permlane32_swap(nrec, nrec, false, false);
             const int n_other = lane_half ? static_cast<int>(sw[0]) : static_cast<int>(sw[1]);
@@ -256,64 +266,69 @@ sweep_xstat_f16_kernel(XsArgs a) {
             // record slots by hand-written ds_reads: in front of a compiler-generated LDS read the compiler
             // drains the vector-memory queue (it cannot know the slots never alias an LDS-DMA in flight),
             // which here would wait for the acknowledgement of the previous stage's fill stores
-            static_assert(kXsSlots == 6, "the asm below reads six slots");
-            unsigned long long rr[kXsSlots];
-            asm volatile("ds_read_b64 %0, %6\n\t"
-                         "ds_read_b64 %1, %6 offset:512\n\t"
-                         "ds_read_b64 %2, %6 offset:1024\n\t"
-                         "ds_read_b64 %3, %6 offset:1536\n\t"
-                         "ds_read_b64 %4, %6 offset:2048\n\t"
-                         "ds_read_b64 %5, %6 offset:2560\n\t"
+            unsigned rr[4];
+            asm volatile("ds_read_b32 %0, %4\n\t"
+                         "ds_read_b32 %1, %4 offset:256\n\t"
+                         "ds_read_b32 %2, %4 offset:512\n\t"
+                         "ds_read_b32 %3, %4 offset:768\n\t"
                          "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3]), "=&v"(rr[4]), "=&v"(rr[5])
+                         : "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3])
                          : "v"(ring_addr)
                          : "memory");
+            const int hb0 = blk0 * kXsHT + lane_h, hb1 = blk1 * kXsHT + 32 + lane_h;
+            auto put = [&](int j, unsigned rec) {
+                if (j < mine && pos + j < cap_part) {
+                    const unsigned q = rec & 15u;
+                    const int h = ((rec & 16u) ? hb1 : hb0) + static_cast<int>(8u * (q >> 2) + (q & 3u));
+                    list[pos + j] = make_uint2(rec & 0xFFFFFFE0u, static_cast<unsigned>(h));
+                }
+            };
             // slot j holds a record only for lanes with more than j of them: stop at the first empty level
             // (typically two or three)
-            auto put = [&](int j) {
-                if (j < mine && pos + j < cap_part)
-                    list[pos + j] = make_uint2(static_cast<unsigned>(rr[j]), static_cast<unsigned>(rr[j] >> 32) & 0x07FFFFFFu);
-            };
-            put(0);
+            put(0, rr[0]);
             if (__builtin_amdgcn_ballot_w64(mine > 1) != 0ull) {
-                put(1);
+                put(1, rr[1]);
                 if (__builtin_amdgcn_ballot_w64(mine > 2) != 0ull) {
-                    put(2);
-                    if (__builtin_amdgcn_ballot_w64(mine > 3) != 0ull) {
-                        put(3);
-                        put(4);
-                        put(5);
+                    put(2, rr[2]);
+                    put(3, rr[3]);
+                    if (__builtin_amdgcn_ballot_w64(mine > 4) != 0ull) {
+                        static_assert(kXsSlots == 9, "the asm below reads slots 4..8");
+                        unsigned r2[5];
+                        asm volatile("ds_read_b32 %0, %5 offset:1024\n\t"
+                                     "ds_read_b32 %1, %5 offset:1280\n\t"
+                                     "ds_read_b32 %2, %5 offset:1536\n\t"
+                                     "ds_read_b32 %3, %5 offset:1792\n\t"
+                                     "ds_read_b32 %4, %5 offset:2048\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(r2[0]), "=&v"(r2[1]), "=&v"(r2[2]), "=&v"(r2[3]), "=&v"(r2[4])
+                                     : "v"(ring_addr)
+                                     : "memory");
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) put(4 + j, r2[j]);
                     }
                 }
             }
             count += (nrec < kXsSlots ? nrec : kXsSlots) + (n_other < kXsSlots ? n_other : kXsSlots);
             if (nrec > kXsSlots || n_other > kXsSlots) count = cap_part + 1;  // lost records: exact fallback
             asm volatile("" ::: "memory");
-            nrec = 0;
+            waddr = ring_addr;
         }
     };
-    // One value of the filter: accumulator register q of row tile mt, stage st (bias quad bq = rows 8g..8g+3
-    // [+4 for the upper half-wave] of that tile, g = q / 4).
-    auto filter_value = [&](int mt, int q, unsigned tag, const f32x4& bq) {
+    // One value of the filter: accumulator register q of row tile mt (bias quad bq = rows 8g..8g+3 [+4 for the upper
+    // half-wave] of that tile, g = q / 4).  EXEC <- !(v < thr) (at or above the threshold, or NaN); the hit lanes write
+    // their record and advance their write position; EXEC <- all.  After every fourth value the position is clamped.
+    auto filter_value = [&](int mt, int q, const f32x4& bq) {
         const float v = fmaf(acc[mt][q], inv_r, bq[q & 3]);
-        const unsigned t = tag + static_cast<unsigned>(mt * 32 + 8 * (q >> 2) + (q & 3));
-        const unsigned long long data = (static_cast<unsigned long long>(t) << 32) | __float_as_uint(v);
-        const unsigned slot = static_cast<unsigned>(nrec < kXsSlots ? nrec : kXsSlots);
-        const unsigned addr = ring_addr + slot * 512u;
+        const unsigned rec = (__float_as_uint(v) & 0xFFFFFFE0u) | static_cast<unsigned>(mt * 16 + q);
         const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_r;
-        // EXEC <- !(v < thr) (at or above the threshold, or NaN); write; EXEC <- all; nrec += hit
         asm volatile("v_cmpx_nlt_f32_e32 vcc, %[v], %[thr]\n\t"
-                     "ds_write_b64 %[addr], %[data]\n\t"
-                     "s_mov_b64 exec, -1\n\t"
-                     "v_addc_co_u32_e32 %[n], vcc, 0, %[n], vcc"
-                     : [n] "+v"(nrec)
-                     : [v] "v"(v), [thr] "v"(cmp), [addr] "v"(addr), [data] "v"(data)
+                     "ds_write_b32 %[addr], %[rec]\n\t"
+                     "v_add_u32_e32 %[addr], 0x100, %[addr]\n\t"
+                     "s_mov_b64 exec, -1"
+                     : [addr] "+v"(waddr)
+                     : [v] "v"(v), [thr] "v"(cmp), [rec] "v"(rec)
                      : "vcc", "memory");
-    };
-    // hidden index of accumulator register 0 of row tile 0 for this lane in stage st, tagged with its row
-    auto stage_tag = [&](int blk) {
-        return static_cast<unsigned>(blk * kXsHT + a.hidden_offset + 4 * lane_half) |
-               (static_cast<unsigned>(lane_col) << 27);
+        if ((q & 3) == 3) waddr = waddr < ring_limit ? waddr : ring_limit;
     };
     auto load_bias = [&](int it, int mt, f32x4 (&bq)[4]) {
         const char* bb = bias_lds + (it % 3) * BIAS_BYTES + 16 * lane_half + mt * 128;
@@ -434,10 +449,9 @@ sweep_xstat_f16_kernel(XsArgs a) {
             return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
         };
         f32x4 bq[4];
-        const unsigned tag = stage_tag(fblk);
         if (FILTER && with_filter) load_bias(fit, fmt, bq);
         auto epilogue = [&](int qv) {
-            if (FILTER && with_filter) filter_value(fmt, qv, tag, bq[qv >> 2]);
+            if (FILTER && with_filter) filter_value(fmt, qv, bq[qv >> 2]);
         };
         f16x8 w0 = rd(0), w1 = rd(1), w2, w3;
         f32x16 c;
@@ -491,21 +505,22 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // Written once, instantiated for the pilot loop and the sweep loop (two loops, so that the pilot's maxima
     // do not occupy registers during the sweep).
     auto iteration = [&](int it, bool first) __attribute__((always_inline)) {
-        const int blk = block_of(it);
-        flush();                                             // older than the DMA issued next
+        // records in the slots: row tile 0 of the previous iteration's block, row tile 1 of the one before it
+        flush(block_of(it > 0 ? it - 1 : 0), block_of(it > 1 ? it - 2 : 0));   // older than the DMA issued next
         stamp(0);
         const bool dma = ld < n_iter;                        // iteration it+1 -> the buffer read during it-1
         fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
         // first pass: epilogue of the previous iteration's row tile 1 (none at the first pilot / first sweep iteration)
-        tile_pass(sbase, 0, !first, 1, block_of(it > 0 ? it - 1 : 0), it - 1, 0, dma);
+        tile_pass(sbase, 0, !first, 1, 0, it - 1, 0, dma);
         if (dma) ++ld;
-        // a lane that already holds four records could overflow its six slots in the second pass: flush now
-        // (rare; the stores are younger than the stage's DMA, which only makes the wait below stricter)
-        if (__builtin_amdgcn_ballot_w64(nrec > kXsSlots - 3) != 0ull) flush();
+        // a lane that already holds five records could overflow its nine slots in the second pass: flush now (only
+        // row tile 1 records of the previous block are there; rare; the stores are younger than the stage's DMA,
+        // which only makes the wait below stricter)
+        if (__builtin_amdgcn_ballot_w64(waddr > ring_addr + 4u * 256u) != 0ull) flush(0, block_of(it > 0 ? it - 1 : 0));
         stamp(2);
-        tile_pass(sbase, 1, true, 0, blk, it, 1, false);
+        tile_pass(sbase, 1, true, 0, 0, it, 1, false);
         stamp(3);
         while (fill_left > 0) fill_one();                    // (budgets beyond the 16 slots of a stage)
         // retire iteration it+1 (for every wave) before anyone reads it; also frees this iteration's buffer
@@ -556,19 +571,20 @@ sweep_xstat_f16_kernel(XsArgs a) {
         for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * kXsWaves + wave) * 8 + i] = tacc[i];
     }
     if (FILTER && n_iter > ps) {
+        // what the last iteration left (tile 0 of the last block, tile 1 of the one before), then the last block's tile 1
+        flush(block_of(n_iter - 1), block_of(n_iter > 1 ? n_iter - 2 : 0));
         f32x4 bq[4];
         load_bias(n_iter - 1, 1, bq);
-        const unsigned tag = stage_tag(block_of(n_iter - 1));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) filter_value(1, q, tag, bq[q >> 2]);
+        for (int q = 0; q < 16; ++q) filter_value(1, q, bq[q >> 2]);
     }
-    flush();
+    flush(0, block_of(n_iter - 1));
     if (row_ok && lane_half == 0) my_cnt[row] = count;
 }
 
 inline bool xstat_supported(int D, int Hs, int hidden_offset) {
     return (D == 512 || D == 256 || D == 128) && Hs > 0 && Hs % kXsHT == 0 && hidden_offset % 4 == 0 &&
-           static_cast<int64_t>(hidden_offset) + Hs <= (1 << 27);      // 27-bit hidden index in a ring record
+           static_cast<int64_t>(hidden_offset) + Hs <= (1 << 30);
 }
 
 // hidden-range split for small batches: double while the grid stays within the chip's 256 CUs, the stage
@@ -583,7 +599,7 @@ inline int xstat_parts(int B, int Hs, int cap) {
 template <int KB, int ABL = 0>
 inline int launch_xstat_one(const XsArgs& a, hipStream_t stream) {
     constexpr size_t lds = static_cast<size_t>(kXsStages) * kXsHT * 16 * KB * 2 +
-                           3 * kXsHT * 4 + static_cast<size_t>(kXsWaves) * (kXsSlots + 1) * 512;
+                           3 * kXsHT * 4 + static_cast<size_t>(kXsWaves) * kXsRingSlots * 256;
     auto kern = sweep_xstat_f16_kernel<KB, ABL>;
     static bool configured = false;
     if (!configured) {
