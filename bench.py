@@ -142,6 +142,7 @@ def secondary_configs(device, x):
             "(~200 active units per row): z bits from the fp16 candidate sweep + exact re-evaluation at the cutoff, "
             "decoder walks the active units; bit-identical to the dense kernels", m, lambda mm, xx: mm(xx), B, 4.0 * D * H)
         m.bits_path = "dense"
+        m.decoder.SPARSE_MAX_ACTIVE_FRACTION = 0.0         # dense decoder whatever the activation density
         run("config 4, same model through the exact dense kernels only (fp32 MFMA encoder + dense decoder)", m,
             lambda mm, xx: mm(xx), B, 4.0 * D * H)
         m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)

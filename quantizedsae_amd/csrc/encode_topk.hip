@@ -1014,7 +1014,7 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
 constexpr int kBitsWaves = 4;
 constexpr int kBitsMaxUnc = 256;      // latents per row inside the uncertainty band (more -> flagged)
 constexpr int kBitsChunk = 8192;      // flagged rows per exact fallback launch
-constexpr int kBitsCap = 2048;        // list entries per row: ~2.5 % of 32768 units active plus the uncertainty band (denser
+constexpr int kBitsCap = 4096;        // list entries per row: ~10 % of 32768 units active plus the uncertainty band (denser
                                       // rows also overflow the sweep's 6 records per lane and 32 latents, and are flagged)
 constexpr int kBitsSets = 3;          // W blocks in flight per wave (of D/32): 8 x 16-byte loads per lane each
 __host__ __device__ static inline size_t bits_lds_per_wave(int H) {

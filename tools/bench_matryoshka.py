@@ -47,8 +47,10 @@ for shift in shifts:
     assert torch.equal(l0, l1) and torch.equal(c0, c1)
     del l0, l1
     m.bits_path = "dense"
+    m.decoder.SPARSE_MAX_ACTIVE_FRACTION = 0.0             # dense decoder whatever the activation density
     t_fwd_dense, _ = timed(lambda: m(x))
     m.bits_path = "auto"
+    del m.decoder.SPARSE_MAX_ACTIVE_FRACTION
     t_fwd_auto, _ = timed(lambda: m(x))
     print(json.dumps(dict(bias_shift_sigmas=shift, active_per_row=round(float(c0.sum()) / B, 1), flagged_rows=flagged,
                           encode_bits_dense_ms=round(t_bits_dense, 3), encode_bits_prefilter_ms=round(t_bits_pref, 3),
