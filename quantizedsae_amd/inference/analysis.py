@@ -201,3 +201,85 @@ def compute_activation_stats(sae: SAEWrapper, loader: Iterable[Any], *, token_id
                     _tokens_per_feature(nz[:, 1], batch_tok.to(dev)[nz[:, 0]], H, tokens_per_feature)
             global_index += B
     return {"activation_counts": counts.cpu(), "coactivation": coact.cpu(), "tokens_per_feature": tokens_per_feature}
+
+
+def compute_reconstruction_error_by_level(sae: SAEWrapper, loader: Iterable[Any], device: Optional[Any] = None) -> torch.Tensor:
+    """Per-level reconstruction MSE (dynamic_analysis.py:103-165): matryoshka = every cumulative level against the
+    input; residual = every stage's reconstruction against the residual it was given (the training objective);
+    other SAEs a length-1 tensor with the overall MSE.  Squared errors are summed on the device in fp64
+    (qsae_sq_err_sum) and read once at the end."""
+    if device is not None:
+        sae.to(device)
+    sae.eval()
+    model = sae.model
+    if not isinstance(model, (QuantizedMatryoshkaSAE, ResidualQuantizedSAE)):
+        return torch.tensor([compute_reconstruction_error(sae, loader)], dtype=torch.float64)
+    sums: Optional[List[torch.Tensor]] = None
+    n_elements = 0
+    with torch.no_grad():
+        for batch in loader:
+            x = _ensure_tensor(batch).to(sae.device)
+            x = x if x.dtype == torch.float32 else x.float()
+            _groups, levels = model(x)
+            if sums is None:
+                sums = [torch.zeros((), dtype=torch.float64, device=sae.device) for _ in levels]
+            target = x.contiguous()
+            for i, recon in enumerate(levels):
+                ops.sq_err_sum(recon, target, sums[i])
+                if isinstance(model, ResidualQuantizedSAE):
+                    target = ((target - recon) * 2).contiguous()
+            n_elements += x.numel()
+    if sums is None:
+        raise ValueError("empty loader")
+    return torch.stack(sums).cpu() / float(max(n_elements, 1))
+
+
+def analyze_dataset(sae: SAEWrapper, loader: Iterable[Any], *, token_ids: torch.Tensor, tokens_per_context: int,
+                    device: Optional[Any] = None, with_tokens: bool = True) -> Dict[str, Any]:
+    """One pass over the data: final reconstruction MSE, activation counts, co-activation matrix and tokens per
+    feature (dynamic_analysis.py:317-440; same result keys, ``mse_per_level`` / ``l0_per_level`` are None there
+    too).  Top-k variants run ``forward_compact`` once per batch and feed its (idx, val, reconstruction) to the
+    integer kernels and the fp64 squared-error sum; the threshold variants take the reconstruction from the
+    forward pass and the masks from the bit-packed encoder output."""
+    if device is not None:
+        sae.to(device)
+    sae.eval()
+    model = sae.model
+    H = _hidden_dim(sae)
+    dev = sae.device
+    counts = torch.zeros((H,), dtype=torch.int64, device=dev)
+    coact = torch.zeros((H, H), dtype=torch.int32, device=dev)
+    sq = torch.zeros((), dtype=torch.float64, device=dev)
+    tokens_per_feature: List[List[int]] = [[] for _ in range(H)]
+    global_index, n_elements = 0, 0
+    compact = isinstance(model, (BinarySAE, BaselineSparseAutoencoder))
+    with torch.no_grad():
+        for batch in loader:
+            x = _ensure_tensor(batch).to(dev)
+            x = (x if x.dtype == torch.float32 else x.float()).contiguous()
+            B = x.shape[0]
+            flat = torch.arange(global_index, global_index + B, dtype=torch.long)
+            batch_tok = token_ids[torch.div(flat, tokens_per_context, rounding_mode="floor"), flat % tokens_per_context]
+            if compact:
+                idx, val, recon = model.forward_compact(x)
+                ops.sq_err_sum(recon, x, sq)
+                ops.activation_counts(idx, val, H, counts)
+                ops.coactivation_sparse(idx, val, H, coact)
+                if with_tokens:
+                    on = val > 0
+                    rows = torch.arange(B, device=dev).unsqueeze(1).expand_as(idx)[on]
+                    _tokens_per_feature(idx[on].long(), batch_tok.to(dev)[rows], H, tokens_per_feature)
+            else:
+                ops.sq_err_sum(sae(x)["reconstruction"].to(dev).contiguous(), x, sq)
+                mask = _activation_mask(sae, x).to(dev)
+                counts += mask.sum(dim=0)
+                pad = (-mask.shape[0]) % 4
+                mt = torch.nn.functional.pad(mask.t().float(), (0, pad)).contiguous()
+                coact += ops.encode_dense(mt, mt, None, ops.ACT_NONE).to(torch.int32)
+                if with_tokens:
+                    nz = mask.nonzero(as_tuple=False)
+                    _tokens_per_feature(nz[:, 1], batch_tok.to(dev)[nz[:, 0]], H, tokens_per_feature)
+            global_index += B
+            n_elements += x.numel()
+    return {"mse_final": float(sq.item()) / max(n_elements, 1), "mse_per_level": None, "l0_per_level": None,
+            "activation_counts": counts.cpu(), "coactivation": coact.cpu(), "tokens_per_feature": tokens_per_feature}

@@ -126,6 +126,72 @@ def test_matryoshka_mask_and_l0_match_reference_bits():
     assert np.array_equal(st["coactivation"].numpy(), want_co)
 
 
+@pytest.mark.parametrize("name", ["binary_small", "baseline_small", "matryoshka_small"])
+def test_analyze_dataset_one_pass(name):
+    """analyze_dataset (dynamic_analysis.py:317-440): one pass = the separate helpers' results + the final MSE, which
+    is checked against the reference's own reconstruction (golden fixture)."""
+    fx = Fixture(name)
+    m, sd = fx.meta, fx.state_dict()
+    if m["variant"] == "binary":
+        model = _load(BinarySAE(m["D"], m["H"], gamma=m["gamma"], n_bits=m["n_bits"]), sd)
+        model.k = m["k"] / m["H"]
+        sae = _wrap("b_sae", model)
+    elif m["variant"] == "baseline":
+        model = _load(BaselineSparseAutoencoder(m["D"], m["H"]), sd)
+        sae = _wrap("baseline_sae", model)
+    else:
+        model = _load(QuantizedMatryoshkaSAE(m["D"], m["H"], 32, abs_range=m["abs_range"], n_bits=m["n_bits"]), sd)
+        sae = _wrap("q_sae", model)
+    x = fx.x()
+    n = len(x)
+    tokens = (torch.arange(n, dtype=torch.long) * 7 + 2).reshape(n, 1)
+    cut = max(1, n // 3)
+    loader = [torch.from_numpy(x[:cut]), [torch.from_numpy(x[cut:])]]
+    st = A.analyze_dataset(sae, loader, token_ids=tokens, tokens_per_context=1, device=DEV)
+    assert set(st) == {"mse_final", "mse_per_level", "l0_per_level", "activation_counts", "coactivation", "tokens_per_feature"}
+    assert st["mse_per_level"] is None and st["l0_per_level"] is None
+    sep = A.compute_activation_stats(sae, loader, token_ids=tokens, tokens_per_context=1)
+    assert torch.equal(st["activation_counts"], sep["activation_counts"])
+    assert torch.equal(st["coactivation"], sep["coactivation"])
+    assert st["tokens_per_feature"] == sep["tokens_per_feature"]
+    assert st["mse_final"] == pytest.approx(A.compute_reconstruction_error(sae, loader), rel=1e-12)
+    ref_recon = fx["reconstruction_levels"][-1] if m["variant"] == "matryoshka" else fx["reconstruction"]
+    if len(ref_recon) == n:
+        want = float(((ref_recon.astype(np.float64) - x) ** 2).mean())
+        assert st["mse_final"] == pytest.approx(want, rel=2e-5)
+
+
+def test_reconstruction_error_by_level():
+    """matryoshka: every cumulative level against the input; residual: every stage against its own residual
+    (dynamic_analysis.py:103-165); top-k models: a length-1 tensor."""
+    from quantizedsae_amd import ResidualQuantizedSAE
+    fx = Fixture("matryoshka_small")
+    m, sd = fx.meta, fx.state_dict()
+    model = _load(QuantizedMatryoshkaSAE(m["D"], m["H"], 32, abs_range=m["abs_range"], n_bits=m["n_bits"]), sd)
+    sae = _wrap("q_sae", model)
+    x = fx.x()
+    loader = [torch.from_numpy(x[:5]), torch.from_numpy(x[5:])]
+    got = A.compute_reconstruction_error_by_level(sae, loader).numpy()
+    want = np.array([((lv.astype(np.float64) - x) ** 2).mean() for lv in fx["reconstruction_levels"]])
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    # residual SAE: against a torch restatement of the reference loop on the model's own outputs
+    torch.manual_seed(3)
+    rq = ResidualQuantizedSAE(64, 512, top_k=8, abs_range=1.5, n_bits=3).to(DEV).eval()
+    xr = torch.randn(40, 64)
+    got = A.compute_reconstruction_error_by_level(_wrap("rq_sae", rq), [xr[:16], xr[16:]])
+    _, levels = rq(xr.to(DEV))
+    residual, want = xr.to(DEV), []
+    for recon in levels:
+        want.append(float(((recon - residual).double() ** 2).mean()))
+        residual = (residual - recon) * 2
+    np.testing.assert_allclose(got.numpy(), np.array(want), rtol=1e-6)
+    # top-k model
+    fb = Fixture("baseline_small")
+    base = _load(BaselineSparseAutoencoder(fb.meta["D"], fb.meta["H"]), fb.state_dict())
+    one = A.compute_reconstruction_error_by_level(_wrap("baseline_sae", base), [torch.from_numpy(fb.x())])
+    assert one.shape == (1,) and one.dtype == torch.float64
+
+
 # ---- SURVEY 8f ranks 3/4: chunk datasets, activation quantizers, BinaryLatentSAE --------------------------------
 def test_quantize_bits_kernel_matches_oracle_and_reference():
     ops = _ops()
