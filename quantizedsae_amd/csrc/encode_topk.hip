@@ -47,6 +47,8 @@ static int g_inkernel_pilot = 1;   // the stationary sweep derives tau itself (n
 static int g_inkernel_rank = 0;    // tau = this rank among the row's 32 group maxima; 0 = from k (inkernel_rank)
 static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
 static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
+static int g_fill_co = 1;          // zeros from a co-resident fill kernel on a second stream (0: inside the sweep; > 1: that many fill waves)
+constexpr int kFillCoWaves = 640;  // fill waves beside the sweep: enough to finish with it, few enough not to crowd its issue slots
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
 static unsigned long long* g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
 static int g_ref_ablate = 0;        // timing experiments on the refine kernel (results wrong when non-zero)
@@ -869,6 +871,45 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     stamp(5);
 }
 
+// Zero-fill of the dense latent by a kernel that runs BESIDE the sweep.  Carried by the sweep's own waves the 8.4 M
+// 1-KiB stores cost it 0.5 ms: a wave that waits for a slot in the write queue cannot issue its next MFMA either.
+// The sweep's no-fill build takes 248 VGPRs per wave, two waves per SIMD, which leaves 16 registers per SIMD -- room
+// for one wave of this kernel (10 VGPRs, no LDS), whose stalls hold up nobody.  Single-wave workgroups, grid-stride
+// over 1-KiB pieces (all waves together write one contiguous run per step), nontemporal stores.  Measured over the
+// number of fill waves (same process, ms per step): in-sweep fill 4.92 | 256: 6.60 | 512: 4.84 | 576: 4.65 | 640: 4.55 |
+// 704: 4.57 | 768: 4.59 | 1024: 4.68 -- best where the fill ends with the sweep.
+__global__ void __launch_bounds__(64)
+fill_zero_co_kernel(float* __restrict__ dense, long long ld, int rows, int ppr /* 1-KiB pieces per row */) {
+    const long long total = static_cast<long long>(rows) * ppr;
+    const int lane = threadIdx.x;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long long p = blockIdx.x; p < total; p += gridDim.x) {
+        const long long r = p / ppr;
+        const int c = static_cast<int>(p - r * ppr);
+        __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(dense + r * ld + c * 256) + lane);
+    }
+}
+
+// ~20 us of one sleeping wave in front of the fill kernel on the side stream: the sweep (same dependency, other
+// stream) is resident on every CU by then.  Fill waves that arrived first could sit two to a SIMD and keep a sweep
+// workgroup (496 of a SIMD's 512 registers) off that CU for the whole fill.
+__global__ void __launch_bounds__(64) co_delay_kernel(int ticks /* of the 100 MHz real-time counter */) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < static_cast<unsigned long long>(ticks)) __builtin_amdgcn_s_sleep(32);
+}
+
+// The co-resident fill needs the register budgets above; if a rebuild changes them, fall back to the in-sweep fill.
+static bool co_fill_fits() {
+    static int fits = -1;
+    if (fits < 0) {
+        hipFuncAttributes fa_sweep{}, fa_fill{};
+        const bool ok = hipFuncGetAttributes(&fa_sweep, reinterpret_cast<const void*>(sweep_xstat_f16_kernel<32, 9>)) == hipSuccess &&
+                        hipFuncGetAttributes(&fa_fill, reinterpret_cast<const void*>(fill_zero_co_kernel)) == hipSuccess;
+        fits = (ok && fa_sweep.numRegs <= 248 && fa_fill.numRegs <= 16) ? 1 : 0;
+    }
+    return fits == 1;
+}
+
 static bool prefilter_shape_ok(int B, int D, int H, int k) {
     return use_fused(B, D, H, k) && D % 64 == 0 && D <= kRefMaxD && (H - pilot_width(H)) > 0;
 }
@@ -916,7 +957,16 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     // of every part: its share of the sweep stages plus the pilot iterations)
     const int xs_iters = xstat ? (Hs / kXsHT) / parts + (inkernel ? P / kXsHT : 0) : 0;
     const int fill_cw = xs_iters > 0 ? (32 * (H / 256) / parts + xs_iters - 1) / xs_iters : 0;   // 1-KiB pieces per wave and iteration
-    const bool fill_in_sweep = xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
+    const bool fill_co = xstat && dense && g_fill_co && D == 512 && H % 256 == 0 && dense_ld % 4 == 0 && g_xstat_ablate == 0 &&
+                         co_fill_fits();
+    const bool fill_in_sweep = !fill_co && xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
+    static thread_local hipStream_t side = nullptr;
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (fill_co && !side) {
+        QSAE_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        QSAE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        QSAE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     // 1. fp16 copy of the batch + per-row scale and error margin (the stationary sweep with the in-kernel pilot does
     //    this in its own prologue, straight into registers)
     const bool fuse_prep = inkernel && g_fuse_xprep;
@@ -961,7 +1011,18 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
                       B, Hs, kCandCap, hoff, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H,
                       fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank > 0 ? g_inkernel_rank : inkernel_rank(k), tau,
                       fuse_prep ? x : nullptr, meta, inv, margin, parts, cnt_parts};
-            rc = launch_xstat(D, xa, s, g_xstat_ablate);
+            if (fill_co) QSAE_HIP(hipEventRecord(ev_fork, s));          // everything before the sweep (x prep, earlier users of `dense`)
+            rc = launch_xstat(D, xa, s, fill_co ? 9 : g_xstat_ablate);
+            if (fill_co && rc == QSAE_OK) {
+                QSAE_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+                hipLaunchKernelGGL(co_delay_kernel, dim3(1), dim3(64), 0, side, 2000);     // 20 us
+                QSAE_LAUNCH_CHECK();
+                hipLaunchKernelGGL(fill_zero_co_kernel, dim3(g_fill_co > 1 ? g_fill_co : kFillCoWaves), dim3(64), 0, side, dense,
+                                   static_cast<long long>(dense_ld), B, H / 256);
+                QSAE_LAUNCH_CHECK();
+                QSAE_HIP(hipEventRecord(ev_join, side));
+                QSAE_HIP(hipStreamWaitEvent(s, ev_join, 0));             // refine writes the survivors into the zeros
+            }
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
             using EpiW = EpiFilter<256, 256, 4, 2, true>;
@@ -989,15 +1050,15 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         }
         hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
                            cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps,
-                           fill_in_sweep ? dense : nullptr, dense_ld, parts, cnt_parts);
+                           (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld, parts, cnt_parts);
     }
     QSAE_LAUNCH_CHECK();
     // 6. flagged rows through the exact unfused kernels
     // (with the zeros written by the sweep, refine and the fallback write the survivors straight into the latent)
     rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false,
-                          fill_in_sweep ? dense : nullptr, dense_ld);
+                          (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld);
     if (rc != QSAE_OK) return rc;
-    if (dense && !fill_in_sweep)
+    if (dense && !fill_in_sweep && !fill_co)
         return xstat ? densify_rows(idx, val, B, k, H, dense, dense_ld, s) : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
 }
@@ -1343,6 +1404,11 @@ extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
 }
 
 extern "C" int qsae_debug_last_flagged() { return g_last_flagged; }
+
+extern "C" int qsae_debug_set_fill_co(int v) {
+    g_fill_co = v;
+    return QSAE_OK;
+}
 
 extern "C" int qsae_debug_set_xstat_rot(int rot) {
     g_pilot_tile = rot >= 1000 ? 1 : 0;                      // rot >= 1000: 256 x 128 pilot tile (timing comparison)

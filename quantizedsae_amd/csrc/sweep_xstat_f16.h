@@ -358,10 +358,11 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const long long fill_step = fill_linear ? static_cast<long long>(kXsWaves - 1) * a.fill_cw : 0;
     // One piece per call, at most a.fill_cw per stage; the calls sit between the MFMA groups of the stage
     // (a burst of nine 1-KiB stores at the top of a stage overruns the write queues and stalls the wave).
+    constexpr bool FILL = ABL != 9;                          // ABL 9: no fill code at all (the zeros come from a co-resident fill kernel)
     int fill_left = 0, nfill = 0;                            // budget / store instructions issued this stage
     int fill_r = 0, fill_c = 0;
     auto fill_begin_stage = [&]() {
-        if (a.dense) {
+        if (FILL && a.dense) {
             fill_left = a.fill_cw;
             nfill = 0;
             fill_r = static_cast<int>(fill_next) / fill_ppr;
@@ -369,7 +370,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
         }
     };
     auto fill_one = [&]() {
-        if (fill_left > 0) {                                 // wave-uniform
+        if (FILL && fill_left > 0) {                         // wave-uniform
             if (fill_next < fill_total) {
                 float* base = a.dense + (fill_row0 + fill_r) * a.dense_ld + fill_c * 256;      // wave-uniform
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -561,7 +562,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
     }
 #pragma unroll 1
     for (int it = ps; it < n_iter; ++it) iteration(it, it == ps);
-    while (a.dense && fill_next < fill_total) {              // (quota * iterations covers the block; safety net)
+    while (FILL && a.dense && fill_next < fill_total) {              // (quota * iterations covers the block; safety net)
         fill_begin_stage();
         while (fill_left > 0) fill_one();
     }
@@ -621,6 +622,7 @@ inline int launch_xstat(int D, const XsArgs& a, hipStream_t stream, int ablate =
     if (D == 512 && ablate == 6) return launch_xstat_one<32, 6>(a, stream);
     if (D == 512 && ablate == 7) return launch_xstat_one<32, 7>(a, stream);
     if (D == 512 && ablate == 8) return launch_xstat_one<32, 8>(a, stream);
+    if (D == 512 && ablate == 9) return launch_xstat_one<32, 9>(a, stream);
     switch (D) {
         case 512: return launch_xstat_one<32>(a, stream);
         case 256: return launch_xstat_one<16>(a, stream);
