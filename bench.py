@@ -266,8 +266,10 @@ def main():
             achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
             kname = (f"sweep_xstat_f16_kernel<32> (fp16 MFMA candidate sweep {B}x512 @ 512x{int(round(H * sweep_frac))}: "
                      "activation panel stationary in registers, weights streamed once per workgroup, in-kernel pilot pass and "
-                     "threshold, threshold filter in the MFMA shadows, plus the zero-fill of the dense [B,32768] latent)")
-            tkey = "sweep_xstat_f16"
+                     "threshold, threshold filter in the MFMA shadows) together with fill_zero_co_kernel, which writes the zeros of "
+                     "the dense [B,32768] latent from the 16 VGPRs per SIMD the sweep leaves free (second stream, joined before "
+                     "the refinement); avg_kernel_ms is the HIP-event time of the pair")
+            tkey = "sweep_xstat_f16+fill_zero_co"
         elif sweep_n:
             enc_ms, peak = sweep_ms, PEAK_FP32_MFMA_TFLOPS
             achieved = sweep_frac * FLOPS_PER_ROW_ENCODER * B / (enc_ms * 1e-3) / 1e12
@@ -314,9 +316,9 @@ def main():
             "fp32_only_path": fp32_ref,
         }
         if path_used == "prefilter" and sweep_n and enc_ms:
-            # The launch carries two resources: 2.06 PFLOP of fp16 MFMA (0.82 ms at peak) and the 8.6 GB of zeros of
-            # the dense latent (1.07 ms at 8 TB/s).  The second one binds, so it is the roofline quoted first; the
-            # MFMA view of the same launch follows under "also".
+            # The sweep / fill pair carries two resources: 2.06 PFLOP of fp16 MFMA (0.82 ms at peak) and the 8.6 GB of
+            # zeros of the dense latent (1.07 ms at 8 TB/s).  The second one binds, so it is the roofline quoted first;
+            # the MFMA view of the same interval follows under "also".
             hswept = int(round(H * sweep_frac))
             algo_bytes = 2 * B * D + 2 * hswept * D + 4 * B * H + 8 * 320 * B      # x~, W~ (fp16), zeros, ~320 records/row
             gbps = algo_bytes / (enc_ms * 1e-3) / 1e9

@@ -117,7 +117,9 @@ int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, i
  * return QSAE_ERR_UNSUPPORTED (use qsae_encode_topk_latent).  dense may be NULL.  For D in {128, 256, 512} the
  * candidate pass is one launch (activation rows stationary in registers, fp16 weights streamed once per workgroup)
  * that also derives the row thresholds and writes the zeros of `dense`; the survivors are written by the refinement.
- * One host round trip per call (the count of rows sent through the exact kernels). */
+ * One host round trip per call (the count of rows sent through the exact kernels).  With D = 512 and a dense output the
+ * zeros are written by a second kernel that runs beside the candidate pass on a library-owned side stream, forked from
+ * and joined back into `stream` inside the call (the call stays ordered on `stream`). */
 size_t qsae_prefilter_w_bytes(int H, int D);
 int qsae_prefilter_pack_w(const float* W, const float* bias, int H, int D, void* Wq, float* meta,
                           qsae_stream_t stream);
