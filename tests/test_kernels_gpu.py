@@ -612,3 +612,9 @@ def test_prefilter_degenerate_rows_fall_back(fused_path):
     assert np.array_equal(host(idx)[ok], want_idx[ok])
     assert np.array_equal(host(val)[ok], want_val[ok])
     assert np.array_equal(host(idx)[~ok], want_idx[~ok])   # exact path ranks NaN/inf rows like the oracle
+    # a call that follows one with flagged rows runs the exact pass for the first 32 of them speculatively (count read
+    # on the device while the host waits for it): same results
+    idx2, val2, dense2 = _prefilter(ops, x, W, bias, k)
+    assert torch.equal(idx2, idx) and torch.equal(val2.view(torch.int32), val.view(torch.int32))
+    if dense is not None:
+        assert torch.equal(dense2.view(torch.int32), dense.view(torch.int32))
