@@ -141,6 +141,8 @@ def encode_bits_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     H = W.shape[0]
     b = _f32c(bias, "bias") if bias is not None else None
     lib = _lib.load()
+    if B == 0:
+        return torch.empty((0, (H + 31) // 32), dtype=torch.int32, device=x.device), 0
     need = int(lib.qsae_encode_bits_prefilter_workspace_bytes(B, D, H))
     if need == 0:
         raise ValueError("shape not supported by the fp16 candidate sweep")

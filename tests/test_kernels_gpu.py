@@ -358,6 +358,30 @@ def test_matryoshka_sparse_decode_matches_dense(B, D, H, n_bits, density):
         assert torch.equal(counts, want_counts)
 
 
+def test_empty_batches_through_every_sparse_entry_point():
+    """B = 0 is legal everywhere (the reference's modules accept an empty batch): empty outputs, no launch."""
+    ops = _ops()
+    D, H, k, n_bits = 512, 4096, 8, 4
+    W = dev(S.xavier_uniform(5, H, D, stream=1))
+    bias = torch.zeros((H,), device=DEV)
+    x0 = torch.empty((0, D), device=DEV)
+    Wq, meta = ops.prefilter_pack_w(W, bias)
+    z, flagged = ops.encode_bits_prefilter(x0, W, bias, Wq, meta)
+    assert tuple(z.shape) == (0, H // 32) and flagged == 0 and not ops.encode_bits_prefilter_supported(0, D, H)
+    assert ops.encode_bits(x0, W, bias).shape == (0, H // 32)
+    sd = S.matryoshka_sae_params(6, D, H)
+    w, wm = dev(sd["decoder.weight"]), dev(sd["decoder.weight_mirror"])
+    codes, scale = ops.pack_matryoshka(w, wm, n_bits, 4.0)
+    rows = ops.pack_matryoshka_rows(w, wm)
+    z0 = torch.empty((0, H // 32), dtype=torch.int32, device=DEV)
+    for fn, c in ((ops.decode_matryoshka, codes), (ops.decode_matryoshka_sparse, rows)):
+        levels, counts = fn(z0, H, D, n_bits, c, scale, None, False)
+        assert tuple(levels.shape) == (n_bits, 0, D) and int(counts.sum()) == 0
+    idx0 = torch.empty((0, k), dtype=torch.int32, device=DEV)
+    val0 = torch.empty((0, k), device=DEV)
+    assert int(ops.activation_counts(idx0, val0, H).sum()) == 0
+
+
 def test_error_codes():
     from quantizedsae_amd import _lib
     ops = _ops()
