@@ -916,10 +916,10 @@ static bool prefilter_shape_ok(int B, int D, int H, int k) {
     return use_fused(B, D, H, k) && D % 64 == 0 && D <= kRefMaxD && (H - pilot_width(H)) > 0;
 }
 
-// Rank among the 32 group maxima (each over H/512 pilot units) that puts about max(4.6 k, 200) values of a row
+// Rank among the 32 group maxima (each over H/512 pilot units) that puts about max(5 k, 200) values of a row
 // above tau: P(group max >= tau) = r/32 = 1 - F^(H/512)  =>  expected count H (1 - F) ~ -512 ln(1 - r/32).
 static int inkernel_rank(int k) {
-    const double target = 4.6 * k > 200.0 ? 4.6 * k : 200.0;
+    const double target = 5.0 * k > 200.0 ? 5.0 * k : 200.0;    // k = 65: rank 15 (13-16 time alike; 15 flags the fewest rows)
     int r = static_cast<int>(32.0 * (1.0 - exp(-target / 512.0)) + 0.5);
     return r < 6 ? 6 : (r > 24 ? 24 : r);
 }
