@@ -129,6 +129,18 @@ int qsae_encode_topk_prefilter(const float* x, const float* W, const float* bias
                                float* dense, int64_t dense_ld, void* workspace, size_t workspace_bytes,
                                qsae_stream_t stream);
 
+/* BinarySAE.forward in one call (sae/binary.py:91-103 with binary_decoder.forward, :24-47, on the k kept entries):
+ * qsae_encode_topk_prefilter followed by qsae_decode_binary_sparse, with the decode of a row done by the refinement
+ * kernel as soon as it has ranked the row (its dictionary gathers and integer converts fill issue slots that the
+ * refinement's own gathers leave idle; rows that take the exact fallback are decoded afterwards).  Outputs are
+ * bit-identical to the two separate calls.  packed from qsae_pack_binary; same workspace and shape limits as
+ * qsae_encode_topk_prefilter; dense may be NULL (compact outputs only). */
+int qsae_binary_forward_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                                  const float* meta, int B, int D, int H, int k, const uint8_t* packed, int n_bits,
+                                  float step, const float* dec_bias, int32_t* idx, float* val, float* dense,
+                                  int64_t dense_ld, float* recon, void* workspace, size_t workspace_bytes,
+                                  qsae_stream_t stream);
+
 /* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
 int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
                  qsae_stream_t stream);

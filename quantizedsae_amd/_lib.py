@@ -39,6 +39,8 @@ SIGNATURES = {
     "qsae_prefilter_pack_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "qsae_encode_topk_prefilter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "qsae_encode_topk_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "qsae_binary_forward_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i64, _vp,
+                                            _vp, _sz, _vp]),
     "qsae_densify": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_binary_row_bytes": (_i, [_i, _i]),
     "qsae_pack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

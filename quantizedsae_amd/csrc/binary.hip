@@ -5,7 +5,7 @@
 // every forward and multiplies the 99.8%-zero dense latent with the full [H, D] matrix.
 // Here the dictionary is packed once to n-bit fields (8 MiB, row h contiguous = one 256-byte
 // gather per selected feature) and the decode touches only the k selected rows.
-#include "common.h"
+#include "decode_row.h"
 
 namespace qsae {
 
@@ -113,59 +113,23 @@ __device__ __forceinline__ void sort_pairs_by_index(bool active, const int32_t* 
     __syncthreads();
 }
 
+// rows != nullptr: row b of this launch is activation row rows[b] (the flagged rows of the prefilter pipeline)
 template <int FW>
 __global__ void __launch_bounds__(64 * kDecWaves)
-decode_binary_sparse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val, int B, int k,
-                            const uint32_t* __restrict__ packed, int H, int D, int n, int row_dwords,
-                            float step, const float* __restrict__ bias, float* __restrict__ recon) {
+decode_binary_sparse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val, int B, int k, int H,
+                            RowDecode d, const int* __restrict__ rows) {
     __shared__ DecShared sh;
     __shared__ int tmp_idx[kDecWaves][kDecMaxK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * kDecWaves + wave;
-    const bool active = b < B;
+    const int slot = blockIdx.x * kDecWaves + wave;
+    const bool active = slot < B;
+    const long long b = active ? (rows ? rows[slot] : slot) : 0;
     int* s_idx = sh.idx[wave];
     float* s_val = sh.val[wave];
-    const long long off = active ? static_cast<long long>(b) * k : 0;
+    const long long off = b * k;
     sort_pairs_by_index(active, idx + off, val + off, k, H, lane, s_idx, s_val, tmp_idx[wave]);
     if (!active) return;
-    constexpr int F = 32 / FW;
-    for (int c = lane; c < row_dwords; c += 64) {
-        float acc[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] = 0.0f;
-        int j = 0;
-        for (; j + 4 <= k; j += 4) {
-            uint32_t w[4];
-            float a[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                w[u] = packed[static_cast<long long>(s_idx[j + u]) * row_dwords + c];
-                a[u] = s_val[j + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int f = 0; f < F; ++f)
-                    acc[f] = fmaf(a[u], static_cast<float>(sbfe_i32(static_cast<int>(w[u]), f * FW, n)), acc[f]);
-        }
-        for (; j < k; ++j) {
-            const uint32_t w = packed[static_cast<long long>(s_idx[j]) * row_dwords + c];
-            const float a = s_val[j];
-#pragma unroll
-            for (int f = 0; f < F; ++f)
-                acc[f] = fmaf(a, static_cast<float>(sbfe_i32(static_cast<int>(w), f * FW, n)), acc[f]);
-        }
-        float* out = recon + static_cast<long long>(b) * D + c * F;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const int d = c * F + f;
-            if (d < D) {
-                float r = step * acc[f];          // rounded multiply, then rounded add (binary.py:38)
-                r = r + (bias ? bias[d] : 0.0f);
-                out[f] = r;
-            }
-        }
-    }
+    decode_row_sorted<FW>(s_idx, s_val, k, d, b, lane);
 }
 
 __global__ void __launch_bounds__(64 * kDecWaves)
@@ -268,6 +232,23 @@ extern "C" int qsae_binary_soft_table(const float* logits, int H, int D, int n_b
     return QSAE_OK;
 }
 
+namespace qsae {
+// rows == nullptr: all B rows; otherwise the nrows rows listed in `rows` (device array)
+int decode_binary_sparse_rows(const int* rows, int nrows, const int32_t* idx, const float* val, int k, int H,
+                              const RowDecode& d, hipStream_t s) {
+    if (nrows <= 0) return QSAE_OK;
+    const dim3 grid((nrows + kDecWaves - 1) / kDecWaves), block(64 * kDecWaves);
+    switch (d.fw) {
+        case 1: hipLaunchKernelGGL(decode_binary_sparse_kernel<1>, grid, block, 0, s, idx, val, nrows, k, H, d, rows); break;
+        case 2: hipLaunchKernelGGL(decode_binary_sparse_kernel<2>, grid, block, 0, s, idx, val, nrows, k, H, d, rows); break;
+        case 4: hipLaunchKernelGGL(decode_binary_sparse_kernel<4>, grid, block, 0, s, idx, val, nrows, k, H, d, rows); break;
+        default: hipLaunchKernelGGL(decode_binary_sparse_kernel<8>, grid, block, 0, s, idx, val, nrows, k, H, d, rows); break;
+    }
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+}  // namespace qsae
+
 extern "C" int qsae_decode_binary_sparse(const int32_t* idx, const float* val, int B, int k,
                                          const uint8_t* packed, int H, int D, int n_bits, float step,
                                          const float* bias, float* recon, qsae_stream_t stream) {
@@ -277,18 +258,9 @@ extern "C" int qsae_decode_binary_sparse(const int32_t* idx, const float* val, i
     QSAE_CHECK_ARG(idx && val && packed && recon, "null pointer");
     QSAE_CHECK_ARG(k >= 1, "k >= 1 required");
     QSAE_CHECK_SUPPORTED(k <= kDecMaxK, "k <= 256");
-    const int fw = field_width(n_bits), row_dwords = qsae_binary_row_bytes(D, n_bits) / 4;
-    const dim3 grid((B + kDecWaves - 1) / kDecWaves), block(64 * kDecWaves);
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(packed);
-    hipStream_t s = as_stream(stream);
-    switch (fw) {
-        case 1: hipLaunchKernelGGL(decode_binary_sparse_kernel<1>, grid, block, 0, s, idx, val, B, k, p, H, D, n_bits, row_dwords, step, bias, recon); break;
-        case 2: hipLaunchKernelGGL(decode_binary_sparse_kernel<2>, grid, block, 0, s, idx, val, B, k, p, H, D, n_bits, row_dwords, step, bias, recon); break;
-        case 4: hipLaunchKernelGGL(decode_binary_sparse_kernel<4>, grid, block, 0, s, idx, val, B, k, p, H, D, n_bits, row_dwords, step, bias, recon); break;
-        default: hipLaunchKernelGGL(decode_binary_sparse_kernel<8>, grid, block, 0, s, idx, val, B, k, p, H, D, n_bits, row_dwords, step, bias, recon); break;
-    }
-    QSAE_LAUNCH_CHECK();
-    return QSAE_OK;
+    const RowDecode d{reinterpret_cast<const uint32_t*>(packed), qsae_binary_row_bytes(D, n_bits) / 4, n_bits,
+                      field_width(n_bits), D, step, bias, recon};
+    return decode_binary_sparse_rows(nullptr, B, idx, val, k, H, d, as_stream(stream));
 }
 
 extern "C" int qsae_decode_table_sparse(const int32_t* idx, const float* val, int B, int k, const float* table,

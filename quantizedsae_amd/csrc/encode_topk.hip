@@ -23,6 +23,7 @@
 #include "gemm_mfma_f32.h"
 #include "gemm_mfma_f32_dma.h"
 #include "sweep_xstat_f16.h"
+#include "decode_row.h"
 
 namespace qsae {
 
@@ -30,6 +31,8 @@ int topk_rows_dispatch(float* latent, int64_t ld, int B, int H, int k, int32_t* 
                        float* tau, uint2* cand, int* cnt, int cap, float* dense, int64_t dense_ld, hipStream_t s,
                        const float* margin = nullptr, int stride = 0);
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
+int decode_binary_sparse_rows(const int* rows, int nrows, const int32_t* idx, const float* val, int k, int H,
+                              const RowDecode& d, hipStream_t s);
 int densify_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
@@ -666,7 +669,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                    const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
                    float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps,
-                   float* __restrict__ dense, int64_t dense_ld, int parts, const int* __restrict__ cnt_parts) {
+                   float* __restrict__ dense, int64_t dense_ld, int parts, const int* __restrict__ cnt_parts, RowDecode dec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
     // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -858,6 +861,10 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     lds_handoff();
     stamp(4);
     // ---- exact rank among the survivors ----------------------------------------------------------------
+    // (with a decoder attached the winners are also kept in LDS, in the W tile's space, which is free by now)
+    int* w_idx = reinterpret_cast<int*>(wt);
+    float* w_val = reinterpret_cast<float*>(wt) + kRefMaxSurv;
+    static_assert(2 * kRefMaxSurv * 4 <= 64 * kRefTileStride * 4, "winner arrays must fit the W tile");
     for (int j = lane; j < m; j += 64) {
         const unsigned long long mine = ekey[j];
         int rank = 0;
@@ -868,9 +875,44 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
             idx_out[static_cast<int64_t>(b) * k + rank] = hi;
             val_out[static_cast<int64_t>(b) * k + rank] = vv;
             if (dense) dense[static_cast<int64_t>(b) * dense_ld + hi] = vv;      // latent * mask; zeros are already there
+            if (dec.packed) {
+                w_idx[rank] = hi;
+                w_val[rank] = vv;
+            }
         }
     }
     stamp(5);
+    // ---- sparse decode of this row (BinarySAE): winners into ascending index order, then the fmaf chain over the
+    // k dictionary rows.  Same code as the stand-alone decode kernel; here its gathers and integer converts run in
+    // the issue slots the other waves' chain gathers leave idle.
+    if (dec.packed) {
+        lds_handoff();
+        int* s_idx = reinterpret_cast<int*>(ekey);                       // the exact keys are no longer needed
+        float* s_val = reinterpret_cast<float*>(ekey) + kRefMaxSurv;
+        int mine_i[(kRefMaxSurv + 63) / 64], pos[(kRefMaxSurv + 63) / 64];
+        float mine_v[(kRefMaxSurv + 63) / 64];
+#pragma unroll
+        for (int t = 0; t < (kRefMaxSurv + 63) / 64; ++t) {
+            const int j = 64 * t + lane;
+            pos[t] = -1;
+            if (64 * t < k && j < k) {
+                mine_i[t] = w_idx[j];
+                mine_v[t] = w_val[j];
+                int p = 0;
+                for (int i = 0; i < k; ++i) p += (w_idx[i] < mine_i[t]) ? 1 : 0;   // hidden indices are distinct
+                pos[t] = p;
+            }
+        }
+        lds_handoff();
+#pragma unroll
+        for (int t = 0; t < (kRefMaxSurv + 63) / 64; ++t)
+            if (pos[t] >= 0) {
+                s_idx[pos[t]] = mine_i[t];
+                s_val[pos[t]] = mine_v[t];
+            }
+        lds_handoff();
+        decode_row_sorted_any(s_idx, s_val, k, dec, b, lane);
+    }
 }
 
 // Zero-fill of the dense latent by a kernel that runs BESIDE the sweep.  Carried by the sweep's own waves the 8.4 M
@@ -926,7 +968,7 @@ static int inkernel_rank(int k) {
 
 static int run_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
                          int B, int D, int H, int k, int32_t* idx, float* val, char* ws, qsae_stream_t stream,
-                         float* dense, int64_t dense_ld) {
+                         float* dense, int64_t dense_ld, const RowDecode* dec = nullptr) {
     hipStream_t s = as_stream(stream);
     const FusedLayout L = fused_layout(B, D, H, k);
     const PrefLayout PL = pref_layout(B, D, L.total);
@@ -1052,7 +1094,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         }
         hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
                            cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps,
-                           (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld, parts, cnt_parts);
+                           (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld, parts, cnt_parts,
+                           dec ? *dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr});
     }
     QSAE_LAUNCH_CHECK();
     // 6. flagged rows through the exact unfused kernels
@@ -1060,6 +1103,11 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false,
                           (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld);
     if (rc != QSAE_OK) return rc;
+    // rows the exact kernels ranked: their reconstruction through the stand-alone decode kernel, by row list
+    if (dec && g_last_flagged > 0) {
+        rc = decode_binary_sparse_rows(flags + 1, g_last_flagged, idx, val, k, H, *dec, s);
+        if (rc != QSAE_OK) return rc;
+    }
     if (dense && !fill_in_sweep && !fill_co)
         return xstat ? densify_rows(idx, val, B, k, H, dense, dense_ld, s) : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
@@ -1562,4 +1610,25 @@ extern "C" int qsae_encode_bits_prefilter(const float* x, const float* W, const 
     QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
     return run_bits_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld,
                               static_cast<char*>(workspace), stream, flagged_rows);
+}
+
+extern "C" int qsae_binary_forward_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                                             const float* meta, int B, int D, int H, int k, const uint8_t* packed,
+                                             int n_bits, float step, const float* dec_bias, int32_t* idx, float* val,
+                                             float* dense, int64_t dense_ld, float* recon, void* workspace,
+                                             size_t workspace_bytes, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0 && k >= 1 && k <= H, "B >= 0, D > 0, H > 0, 1 <= k <= H required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(x && W && Wq && meta && idx && val && packed && recon, "null pointer");
+    QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= 8, "1 <= n_bits <= 8 required");
+    QSAE_CHECK_SUPPORTED(prefilter_shape_ok(B, D, H, k), "shape outside the prefilter's range (use qsae_encode_topk_latent + qsae_decode_binary_sparse)");
+    if (!workspace || workspace_bytes < qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
+        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", __func__);
+    QSAE_CHECK_ARG(aligned16(workspace) && aligned16(x) && aligned16(W) && aligned16(Wq), "16-byte alignment");
+    QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 3u) == 0, "packed must be 4-byte aligned");
+    if (dense) QSAE_CHECK_ARG(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense), "dense latent alignment / ld");
+    const RowDecode d{reinterpret_cast<const uint32_t*>(packed), qsae_binary_row_bytes(D, n_bits) / 4, n_bits,
+                      field_width(n_bits), D, step, dec_bias, recon};
+    return run_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, k, idx, val,
+                         static_cast<char*>(workspace), stream, dense, dense_ld, &d);
 }

@@ -255,6 +255,32 @@ def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     return idx, val, (dense[:, :H] if dense_out is not None else dense)
 
 
+def binary_forward_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                             meta: torch.Tensor, k: int, packed: torch.Tensor, n_bits: int, step: float,
+                             dec_bias: Optional[torch.Tensor], want_dense: bool = True):
+    """encode_topk_prefilter + decode_binary_sparse in one call (rows are decoded by the refinement kernel as it
+    ranks them): (idx, val, dense latent or None, reconstruction), bit-identical to the two separate calls."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    _dev(packed, "packed", torch.uint8)
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    db = _f32c(dec_bias, "dec_bias") if dec_bias is not None else None
+    lib = _lib.load()
+    need = int(lib.qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
+    if need == 0:
+        raise ValueError("shape not supported by the fp16 prefilter")
+    ws = _workspace(x.device, need)
+    idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=x.device)
+    dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
+    recon = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    check(lib.qsae_binary_forward_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(packed), n_bits,
+                                            float(step), _p(db), _p(idx), _p(val), _p(dense), H, _p(recon), _p(ws),
+                                            ws.numel(), _stream()))
+    return idx, val, dense, recon
+
+
 def densify(idx: torch.Tensor, val: torch.Tensor, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(idx, "idx", torch.int32)
     _dev(val, "val", torch.float32)

@@ -115,6 +115,12 @@ class BinarySAE(SparseAutoencoder):
             if self.resolved_latent_path(x.shape[0]) == "prefilter":
                 pw = self._prefilter_weights()
                 xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                if self.decoder.decode_mode == "hard" and self.fuse_decode:
+                    dec = self.decoder
+                    idx, val, _, recon = ops.binary_forward_prefilter(
+                        xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.packed()["packed"],
+                        dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=False)
+                    return idx, val, recon
                 idx, val, _ = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
                                                         self.top_k, want_dense=False)
             else:
@@ -129,6 +135,9 @@ class BinarySAE(SparseAutoencoder):
     #: bit-identical outputs; auto takes prefilter for large batches (fused where its shape limits do not
     #: hold) and inplace for small ones.
     latent_path = "auto"
+    #: prefilter path: the refinement kernel also decodes each row it has ranked (one launch less, the decode's work in
+    #: the refinement's idle issue slots); False = separate decode kernel.  Bit-identical either way.
+    fuse_decode = True
 
     def resolved_latent_path(self, batch_rows: int) -> str:
         """Which path forward() takes for a batch of this many rows (after the auto / shape fallbacks)."""
@@ -162,6 +171,13 @@ class BinarySAE(SparseAutoencoder):
                 else:
                     pw = self._prefilter_weights()
                     xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                    if self.decoder.decode_mode == "hard" and self.fuse_decode:
+                        dec = self.decoder
+                        st = dec.packed()
+                        idx, val, latent, recon = ops.binary_forward_prefilter(
+                            xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, st["packed"],
+                            dec.n_bits, dec.quantization_step, dec.bias.detach())
+                        return latent, recon, st["polarize"]
                     idx, val, latent = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"],
                                                                  pw["meta"], self.top_k)
             if path == "fused":

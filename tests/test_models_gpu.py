@@ -136,6 +136,37 @@ def test_ternary_sae(name):
     assert np.max(np.abs(host(h) - fx["latent"])) < 4e-6
 
 
+@pytest.mark.parametrize("B,H,n_bits", [(2304, 8192, 4), (4096, 32768, 4), (2100, 8192, 8), (2048, 8192, 2)])
+def test_binary_forward_fused_decode_matches_separate_kernels(B, H, n_bits):
+    """BinarySAE.forward with the decode inside the refinement kernel (qsae_binary_forward_prefilter) == prefilter
+    + stand-alone decode kernel, bit for bit, including rows that take the exact fallback (NaN / inf / all-ties)."""
+    D = 512
+    sd = S.binary_sae_params(77, D, H, n_bits, 30.0, 0.05, 0.1)
+    model = load(BinarySAE(D, H, gamma=4.0, n_bits=n_bits), sd)
+    x = S.activations(78, B, D)
+    x[5] = 0.0
+    x[17, 3] = np.nan
+    x[40, 100] = np.inf
+    xd = dev(x)
+    assert model.resolved_latent_path(B) == "prefilter"
+    outs = {}
+    for fuse in (False, True, True):                      # the second fused call runs the speculative fallback
+        model.fuse_decode = fuse
+        lat, rec, pol = model(xd)
+        idx, val, rec_c = model.forward_compact(xd)
+        if fuse not in outs:
+            outs[fuse] = (lat, rec, idx, val, rec_c)
+        else:
+            for a, b_ in zip(outs[fuse], (lat, rec, idx, val, rec_c)):
+                assert torch.equal(a.view(torch.int32), b_.view(torch.int32))
+    for a, b_ in zip(outs[False], outs[True]):
+        assert torch.equal(a.view(torch.int32), b_.view(torch.int32))
+    ok = np.ones(B, bool); ok[[17, 40]] = False
+    want = oracle.binary_forward(x[:64], sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                 sd["decoder.bias"], n_bits=n_bits, gamma=4.0, k=model.top_k)
+    assert np.array_equal(host(outs[True][1])[:64][ok[:64]], want["reconstruction"][ok[:64]])
+
+
 @pytest.mark.parametrize("B,shift", [(4096, -2.5), (2304, -2.0), (2048, 0.0)])
 def test_matryoshka_prefilter_path_matches_dense_path(B, shift):
     """QuantizedMatryoshkaSAE.forward through the candidate sweep + sparse walk == the exact dense kernels, bit for
