@@ -128,6 +128,23 @@ int main(int argc, char** argv) {
     QSAE_OK_OR_DIE(qsae_decode_binary_sparse(didx, dval, B, k, dpacked, H, D, n_bits, step, dbias_dec, drecon, stream));
     QSAE_OK_OR_DIE(qsae_sq_err_sum(drecon, dx, static_cast<size_t>(B) * D, dsq, stream));
     HIP_OK(hipStreamSynchronize(stream));
+    // the same forward as ONE call (the refinement kernel decodes the rows): must reproduce the two-call outputs
+    std::vector<float> frecon;
+    std::vector<int32_t> fidx;
+    if (prefilter) {
+        int32_t* didx2;
+        float *dval2, *drecon2;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&didx2), static_cast<size_t>(B) * k * 4));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&dval2), static_cast<size_t>(B) * k * 4));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&drecon2), static_cast<size_t>(B) * D * 4));
+        QSAE_OK_OR_DIE(qsae_binary_forward_prefilter(dx, dW, dbias_enc, dWq, dmeta, B, D, H, k, dpacked, n_bits, step, dbias_dec,
+                                                     didx2, dval2, nullptr, 0, drecon2, dws, ws_bytes, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        frecon.resize(static_cast<size_t>(B) * D);
+        fidx.resize(static_cast<size_t>(B) * k);
+        HIP_OK(hipMemcpy(frecon.data(), drecon2, frecon.size() * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(fidx.data(), didx2, fidx.size() * 4, hipMemcpyDeviceToHost));
+    }
 
     std::vector<int32_t> gidx(oidx.size());
     std::vector<float> gval(oval.size()), grecon(orecon.size()), gdense(lat.size());
@@ -145,6 +162,8 @@ int main(int argc, char** argv) {
     if (memcmp(gidx.data(), oidx.data(), oidx.size() * 4) != 0) { printf("FAIL top-k indices\n"); return 1; }
     if (memcmp(gval.data(), oval.data(), oval.size() * 4) != 0) { printf("FAIL top-k values\n"); return 1; }
     if (memcmp(grecon.data(), orecon.data(), orecon.size() * 4) != 0) { printf("FAIL reconstruction\n"); return 1; }
+    if (prefilter && (memcmp(frecon.data(), orecon.data(), orecon.size() * 4) != 0 ||
+                      memcmp(fidx.data(), oidx.data(), oidx.size() * 4) != 0)) { printf("FAIL one-call forward\n"); return 1; }
     size_t nonzero = 0;
     for (int b = 0; b < B; ++b) {
         const float* row = gdense.data() + static_cast<size_t>(b) * H;
