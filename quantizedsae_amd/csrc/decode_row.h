@@ -18,7 +18,7 @@ struct RowDecode {
 // s_idx ascending, s_val the matching values (LDS or any memory the whole wave can read).  Every lane owns one dword
 // of the packed row (32/FW output columns) per sweep; the fmaf chain runs in ascending feature index like the
 // oracle's; `* step` and `+ bias` are rounded separately (binary.py:38).
-template <int FW>
+template <int FW, int U = 4>   // U: dictionary rows in flight
 __device__ __forceinline__ void decode_row_sorted(const int* s_idx, const float* s_val, int k, const RowDecode& d,
                                                   long long b, int lane) {
     constexpr int F = 32 / FW;
@@ -27,16 +27,16 @@ __device__ __forceinline__ void decode_row_sorted(const int* s_idx, const float*
 #pragma unroll
         for (int f = 0; f < F; ++f) acc[f] = 0.0f;
         int j = 0;
-        for (; j + 4 <= k; j += 4) {
-            uint32_t w[4];
-            float a[4];
+        for (; j + U <= k; j += U) {
+            uint32_t w[U];
+            float a[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 w[u] = d.packed[static_cast<long long>(s_idx[j + u]) * d.row_dwords + c];
                 a[u] = s_val[j + u];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int f = 0; f < F; ++f)
                     acc[f] = fmaf(a[u], static_cast<float>(sbfe_i32(static_cast<int>(w[u]), f * FW, d.n)), acc[f]);
@@ -61,13 +61,14 @@ __device__ __forceinline__ void decode_row_sorted(const int* s_idx, const float*
     }
 }
 
+template <int U>
 __device__ __forceinline__ void decode_row_sorted_any(const int* s_idx, const float* s_val, int k, const RowDecode& d,
                                                       long long b, int lane) {
     switch (d.fw) {                                  // wave-uniform
-        case 1: decode_row_sorted<1>(s_idx, s_val, k, d, b, lane); break;
-        case 2: decode_row_sorted<2>(s_idx, s_val, k, d, b, lane); break;
-        case 4: decode_row_sorted<4>(s_idx, s_val, k, d, b, lane); break;
-        default: decode_row_sorted<8>(s_idx, s_val, k, d, b, lane); break;
+        case 1: decode_row_sorted<1, U>(s_idx, s_val, k, d, b, lane); break;
+        case 2: decode_row_sorted<2, U>(s_idx, s_val, k, d, b, lane); break;
+        case 4: decode_row_sorted<4, U>(s_idx, s_val, k, d, b, lane); break;
+        default: decode_row_sorted<8, U>(s_idx, s_val, k, d, b, lane); break;
     }
 }
 

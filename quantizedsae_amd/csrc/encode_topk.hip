@@ -911,7 +911,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                 s_val[pos[t]] = mine_v[t];
             }
         lds_handoff();
-        decode_row_sorted_any(s_idx, s_val, k, dec, b, lane);
+        decode_row_sorted_any<4>(s_idx, s_val, k, dec, b, lane);    // (eight gathers in flight: 190 VGPRs, two waves per SIMD, slower)
     }
 }
 
