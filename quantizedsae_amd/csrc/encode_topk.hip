@@ -51,7 +51,8 @@ static int g_inkernel_rank = 0;    // tau = this rank among the row's 32 group m
 static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
 static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
 static int g_fill_co = 1;          // zeros from a co-resident fill kernel on a second stream (0: inside the sweep; > 1: that many fill waves)
-constexpr int kFillCoWaves = 640;  // fill waves beside the sweep: enough to finish with it, few enough not to crowd its issue slots
+constexpr int kFillCoWaves = 1024; // fill waves beside the sweep: one per SIMD, so every sweep wave has the same neighbour
+constexpr int kFillCoPace = 4;     // s_sleep(1) per store: the fill ends with the sweep (measured scan in the kernel's comment)
 static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
 static unsigned long long* g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
 static int g_ref_ablate = 0;        // timing experiments on the refine kernel (results wrong when non-zero)
@@ -919,18 +920,37 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
 // 1-KiB stores cost it 0.5 ms: a wave that waits for a slot in the write queue cannot issue its next MFMA either.
 // The sweep's no-fill build takes 248 VGPRs per wave, two waves per SIMD, which leaves 16 registers per SIMD -- room
 // for one wave of this kernel (10 VGPRs, no LDS), whose stalls hold up nobody.  Single-wave workgroups, grid-stride
-// over 1-KiB pieces (all waves together write one contiguous run per step), nontemporal stores.  Measured over the
-// number of fill waves (same process, ms per step): in-sweep fill 4.92 | 256: 6.60 | 512: 4.84 | 576: 4.65 | 640: 4.55 |
-// 704: 4.57 | 768: 4.59 | 1024: 4.68 -- best where the fill ends with the sweep.
+// over 1-KiB pieces (all waves together write one contiguous run per step), nontemporal stores, paced with s_sleep so
+// that the fill ends when the sweep does (unpaced it finishes early and costs the sweep more while it runs).
+// Same-process scans, ms per step (in-sweep fill: 4.75-4.92):  1024 waves x pace 3 | 4 | 5 | 6: 4.53 | 4.41 | 4.53 | 4.75;
+// 768 x 2: 4.43; 640 x 1: 4.44; unpaced 384-448: 4.51; a first version with a 64-bit division per store (which paced
+// it by accident), 640 waves: 4.41-4.55.  All land on 2.53-2.57 ms for the sweep / fill pair against 2.23 ms for the
+// sweep alone: what is left is the memory system, not issue slots.
 __global__ void __launch_bounds__(64)
-fill_zero_co_kernel(float* __restrict__ dense, long long ld, int rows, int ppr /* 1-KiB pieces per row */) {
-    const long long total = static_cast<long long>(rows) * ppr;
-    const int lane = threadIdx.x;
+fill_zero_co_kernel(float* __restrict__ dense, long long ld, int rows, int ppr /* 1-KiB pieces per row */, int pace) {
+    // piece p = (row r, 1-KiB column block c), p = blockIdx.x, += gridDim.x.  Everything but the lane offset is
+    // wave-uniform and advanced incrementally (a 64-bit division per store would cost this kernel forty instructions
+    // per store -- issue slots it takes from the sweep it runs beside).
+    const int G = static_cast<int>(gridDim.x);
+    const int dr = G / ppr, dc = G % ppr;
+    int r = static_cast<int>(blockIdx.x) / ppr, c = static_cast<int>(blockIdx.x) % ppr;
+    const long long row_bytes = ld * 4;
+    const long long step_bytes = dr * row_bytes + static_cast<long long>(dc) * 1024;
+    const long long wrap_bytes = row_bytes - static_cast<long long>(ppr) * 1024;
+    long long off = r * row_bytes + static_cast<long long>(c) * 1024;
+    char* base = reinterpret_cast<char*>(dense) + threadIdx.x * 16;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = blockIdx.x; p < total; p += gridDim.x) {
-        const long long r = p / ppr;
-        const int c = static_cast<int>(p - r * ppr);
-        __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(dense + r * ld + c * 256) + lane);
+    while (r < rows) {
+        __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(base + off));
+        for (int i = 0; i < pace; ++i) __builtin_amdgcn_s_sleep(1);      // 64 cycles each: spreads the stores over the sweep's duration
+        off += step_bytes;
+        r += dr;
+        c += dc;
+        if (c >= ppr) {
+            c -= ppr;
+            r += 1;
+            off += wrap_bytes;
+        }
     }
 }
 
@@ -1061,8 +1081,8 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
                 QSAE_HIP(hipStreamWaitEvent(side, ev_fork, 0));
                 hipLaunchKernelGGL(co_delay_kernel, dim3(1), dim3(64), 0, side, 2000);     // 20 us
                 QSAE_LAUNCH_CHECK();
-                hipLaunchKernelGGL(fill_zero_co_kernel, dim3(g_fill_co > 1 ? g_fill_co : kFillCoWaves), dim3(64), 0, side, dense,
-                                   static_cast<long long>(dense_ld), B, H / 256);
+                hipLaunchKernelGGL(fill_zero_co_kernel, dim3(g_fill_co > 1 ? g_fill_co % 10000 : kFillCoWaves), dim3(64), 0, side, dense,
+                                   static_cast<long long>(dense_ld), B, H / 256, g_fill_co > 1 ? g_fill_co / 10000 : kFillCoPace);
                 QSAE_LAUNCH_CHECK();
                 QSAE_HIP(hipEventRecord(ev_join, side));
                 QSAE_HIP(hipStreamWaitEvent(s, ev_join, 0));             // refine writes the survivors into the zeros
