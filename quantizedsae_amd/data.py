@@ -50,14 +50,41 @@ class HiddenStatesTorchDataset(Dataset):
         flat = self.data.reshape(self.cum_sizes, self.files_info[3])
         return flat[start:stop].float()
 
-    def iter_batches(self, batch_rows: int, device, world_size: int = 1, rank: int = 0) -> Iterator[torch.Tensor]:
-        """This rank's contiguous slice of the chunk (``sharding.shard_rows``) in device batches."""
+    def iter_batches(self, batch_rows: int, device, world_size: int = 1, rank: int = 0,
+                     prefetch: bool = True) -> Iterator[torch.Tensor]:
+        """This rank's contiguous slice of the chunk (``sharding.shard_rows``) in device batches.
+
+        The stored dtype is shipped (fp16 dumps: half the bytes over PCIe) and widened on the device; fp16/bf16 -> fp32
+        is exact, so the values equal the reference's host-side ``.float()``.  With ``prefetch`` the chunk is page-
+        locked once and batch i+1 is copied on a second stream while batch i is being processed (the forward pass
+        has a host round trip per batch, so a copy issued after it would start when the GPU is already idle)."""
         s, e = shard_rows(self.cum_sizes, world_size, rank)
+        dev = torch.device(device)
+        if not (prefetch and dev.type == "cuda"):
+            flat = self.data.reshape(self.cum_sizes, self.files_info[3])
+            for a in range(s, e, batch_rows):
+                yield flat[a:min(a + batch_rows, e)].to(dev, non_blocking=True).float()
+            return
+        if not self.data.is_pinned():
+            self.data = self.data.pin_memory()
         flat = self.data.reshape(self.cum_sizes, self.files_info[3])
+        copy_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+
+        def issue(a):
+            with torch.cuda.stream(copy_stream):
+                t = flat[a:min(a + batch_rows, e)].to(dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return t, ev
+
+        pending = issue(s) if s < e else None
         for a in range(s, e, batch_rows):
-            # ship the stored dtype (fp16 dumps: half the bytes over PCIe) and widen on the device; fp16/bf16 -> fp32
-            # is exact, so the values equal the reference's host-side .float()
-            yield flat[a:min(a + batch_rows, e)].to(device, non_blocking=True).float()
+            t, ev = pending
+            pending = issue(a + batch_rows) if a + batch_rows < e else None
+            cur.wait_event(ev)
+            t.record_stream(cur)
+            yield t.float()
 
 
 class HiddenStatesTorchDatasetInBinary(HiddenStatesTorchDataset):
