@@ -1,0 +1,140 @@
+"""Parity of the path bench.py measures, at the size it measures it: B = 65536 rows, H = 32768, D = 512.
+
+At this batch the prefilter runs with parts = 1 (one list segment per row, 256 activation panels), the
+co-resident zero-fill kernel over a 2^31-element dense latent, and the refinement kernel decodes every
+row -- none of which the 4096-row tests exercise.  Reference semantics: sae/binary.py:91-103 (BinarySAE.forward),
+sae/baseline.py:17-40 (BaselineSparseAutoencoder.forward).
+
+Checks (size-independent properties + oracle rows):
+  * default path (prefilter) vs the exact-fp32 fused path: idx, val, reconstruction and the WHOLE dense
+    latent bit-identical;
+  * (latent != 0).sum() == B * k;
+  * 64 strided rows bit-exact against the CPU oracle;
+  * one strided dense output (row stride > H) at this size through the C-ABI entry point.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from quantizedsae_amd import BaselineSparseAutoencoder, BinarySAE, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B, D, H, N_BITS, GAMMA = 65536, 512, 32768, 4, 4.0
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+
+
+def make_binary(seed, enc_bias_std=0.02, dec_bias_std=0.1):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    model = BinarySAE(D, H, gamma=GAMMA, n_bits=N_BITS).to(DEV).eval()
+    bound = (6.0 / (D + H)) ** 0.5
+    with torch.no_grad():
+        model.encoder[0].weight.copy_((torch.rand((H, D), device=DEV, generator=g) * 2 - 1) * bound)
+        model.encoder[0].bias.copy_(torch.randn((H,), device=DEV, generator=g) * enc_bias_std)
+        bits = torch.randint(0, 2, (H, D * N_BITS), device=DEV, generator=g, dtype=torch.int8)
+        model.decoder.weight.copy_((bits.float() * 2 - 1) * 30.0)
+        model.decoder.bias.copy_(torch.randn((D,), device=DEV, generator=g) * dec_bias_std)
+    x = torch.randn((B, D), device=DEV, generator=g)
+    return model, x
+
+
+def test_binary_headline_default_path_equals_exact_path_and_oracle():
+    model, x = make_binary(11)
+    k = model.top_k
+    assert k == 65
+    assert model.resolved_latent_path(B) == "prefilter"
+    latent, recon, pol = model(x)
+    idx, val, recon_c = model.forward_compact(x)
+    assert bits_equal(recon_c, recon)
+    # the dense latent is exactly the scatter of (idx, val): k non-zeros per row, B * k in total
+    nnz = int((latent != 0).sum())
+    assert nnz == B * k
+    assert bool(((latent != 0).sum(1) == k).all())
+    assert bits_equal(torch.gather(latent, 1, idx.long()), val)
+    # exact-fp32 fused path: every output bit-identical, including the whole 8 GiB latent
+    model.latent_path = "fused"
+    lat_f, rec_f, _ = model(x)
+    idx_f, val_f, _ = model.forward_compact(x)
+    assert torch.equal(idx_f, idx) and bits_equal(val_f, val)
+    assert bits_equal(rec_f, recon)
+    assert bits_equal(lat_f, latent)
+    del lat_f, rec_f
+    model.latent_path = "auto"
+    # 64 strided rows against the CPU oracle (bit-exact)
+    sel = torch.arange(0, B, B // 64, device=DEV) + 3
+    want = oracle.binary_forward(host(x[sel]), host(model.encoder[0].weight), host(model.encoder[0].bias),
+                                 host(model.decoder.weight), host(model.decoder.bias), n_bits=N_BITS, gamma=GAMMA, k=k)
+    assert np.array_equal(host(idx[sel]), want["idx"])
+    assert np.array_equal(host(val[sel]), want["val"])
+    assert np.array_equal(host(recon[sel]), want["reconstruction"])
+    assert np.array_equal(host(latent[sel]), want["latent"])
+    assert float(pol) == pytest.approx(want["polarize_loss"], rel=1e-5, abs=1e-20)
+
+
+def test_binary_headline_repeatable_and_separate_decode():
+    """Two more batches through the default path: the refinement kernel's fused decode equals the stand-alone
+    decode kernel, and a repeated call returns the same bits (no dependence on workspace contents)."""
+    model, x = make_binary(12, enc_bias_std=0.0, dec_bias_std=0.0)       # the bench configuration: zero biases
+    lat0, rec0, _ = model(x)
+    model.fuse_decode = False
+    lat1, rec1, _ = model(x)
+    assert bits_equal(rec1, rec0) and bits_equal(lat1, lat0)
+    del lat1, rec1
+    model.fuse_decode = True
+    x2 = torch.roll(x, 1, 0)
+    lat2, rec2, _ = model(x2)
+    assert bits_equal(torch.roll(rec2, -1, 0), rec0)
+    assert bits_equal(lat2[1:], lat0[:-1]) and bits_equal(lat2[:1], lat0[-1:])
+
+
+def test_headline_strided_dense_output():
+    """qsae_encode_topk_prefilter with a dense output whose row stride exceeds H (dense_ld = H + 64): the padding
+    columns are untouched, the H used columns equal the contiguous result."""
+    model, x = make_binary(13)
+    lin = model.encoder.linear
+    pw = model._prefilter_weights()
+    k = model.top_k
+    idx0, val0, dense0 = ops.encode_topk_prefilter(x, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], k)
+    ld = H + 64
+    buf = torch.full((B, ld), -7.0, dtype=torch.float32, device=DEV)
+    idx1, val1, dense1 = ops.encode_topk_prefilter(x, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], k,
+                                                   dense_out=buf)
+    assert torch.equal(idx1, idx0) and bits_equal(val1, val0)
+    assert dense1.stride(0) == ld
+    assert bits_equal(dense1.contiguous(), dense0)
+    assert bool((buf[:, H:] == -7.0).all())
+
+
+def test_baseline_headline_default_path_equals_exact_path_and_oracle():
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    model = BaselineSparseAutoencoder(D, H).to(DEV).eval()
+    with torch.no_grad():
+        model.encoder[0].bias.copy_(torch.randn((H,), device=DEV, generator=g) * 0.05)
+    x = torch.randn((B, D), device=DEV, generator=g)
+    k = model.topk
+    assert k == 32
+    h, recon = model(x)                                      # auto -> prefilter
+    assert int((h != 0).sum()) == B * k
+    idx, val, recon_c = model.forward_compact(x)
+    assert bits_equal(recon_c, recon)
+    assert bits_equal(torch.gather(h, 1, idx.long()), val)
+    model.latent_path = "fused"
+    h_f, rec_f = model(x)
+    assert bits_equal(rec_f, recon) and bits_equal(h_f, h)
+    del h_f, rec_f
+    model.latent_path = "auto"
+    sel = torch.arange(0, B, B // 64, device=DEV) + 5
+    want = oracle.baseline_forward(host(x[sel]), host(model.encoder[0].weight), host(model.encoder[0].bias),
+                                   host(model.decoder.weight), host(model.decoder.bias), k=k)
+    assert np.array_equal(host(h[sel]), want["latent"])
+    assert np.array_equal(host(recon[sel]), want["reconstruction"])
