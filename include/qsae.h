@@ -6,7 +6,13 @@
  * point below replaces the ATen call sequence cited next to it (paths relative to the
  * reference root).  Everything here is stateless: plain device pointers and sizes, no
  * torch types, work is enqueued on the given HIP stream and the call returns without
- * synchronising.  The Python host side in quantizedsae_amd/ binds these with ctypes
+ * synchronising (exceptions are marked "one host round trip").  No call leaves anything
+ * behind that a later call reads: what the library keeps is per device ("this kernel's LDS limit
+ * is raised on device d") or owned by one host thread for one device (a side stream, three
+ * events, one pinned word -- created on first use).  Calls may therefore be made from several
+ * host threads and on several devices of one process; the caller makes the device of its
+ * pointers current, as for any HIP library, and gives every concurrently running call its own
+ * workspace.  The Python host side in quantizedsae_amd/ binds these with ctypes
  * (INTEGRATION.md shows the stub a reference maintainer would add).
  *
  * Conventions
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QSAE_ABI_VERSION 1
+#define QSAE_ABI_VERSION 2
 
 #define QSAE_OK 0
 #define QSAE_ERR_INVALID_ARG (-1)  /* null pointer, non-positive dim, misaligned pointer      */
@@ -53,6 +59,16 @@ int qsae_abi_version(void);
 const char* qsae_last_error(void);
 /* Properties of the current device: compute units, name of the gfx target (e.g. "gfx950"). */
 int qsae_device_info(int* cu_count, char* arch, int arch_len);
+
+/* -- profiling ---------------------------------------------------------------------------- */
+/* One-shot, per host thread: the NEXT fused / prefilter / bits-prefilter call of the calling thread records
+ * ev_begin (hipEvent_t) on its stream right before its candidate-sweep launch and ev_end right after it (after the
+ * co-resident fill kernel has joined, where there is one), then forgets them.  NULL, NULL clears a pending pair.
+ * This is how bench.py times the dominant kernel live on the launch stream. */
+int qsae_profile_sweep_events(void* ev_begin, void* ev_end);
+/* Fraction of the encoder's 2 B D H FLOPs that the profiled launch covers for hidden width H (1.0 when the sweep
+ * derives its thresholds itself, else (H - pilot block) / H). */
+double qsae_profile_sweep_flop_fraction(int H);
 
 /* -- encoder ---------------------------------------------------------------------------- */
 /* K-interleaved operand layout.  dst[r][8g + j/2 + 4*(j&1)] = src[r][8g + j]: every 8 consecutive
@@ -117,9 +133,13 @@ int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, i
  * return QSAE_ERR_UNSUPPORTED (use qsae_encode_topk_latent).  dense may be NULL.  For D in {128, 256, 512} the
  * candidate pass is one launch (activation rows stationary in registers, fp16 weights streamed once per workgroup)
  * that also derives the row thresholds and writes the zeros of `dense`; the survivors are written by the refinement.
- * One host round trip per call (the count of rows sent through the exact kernels).  With D = 512 and a dense output the
- * zeros are written by a second kernel that runs beside the candidate pass on a library-owned side stream, forked from
- * and joined back into `stream` inside the call (the call stays ordered on `stream`). */
+ * With D = 512 and a dense output the zeros are written by a second kernel that runs beside the candidate pass on a
+ * side stream owned by the calling thread (one per device), forked from and joined back into `stream` inside the call
+ * (the call stays ordered on `stream`).
+ * One host round trip per call: the number of rows sent through the exact kernels (normally 0-5 of 65536), which also
+ * comes back in *flagged_rows (host int, may be NULL).  spec_rows > 0 lets the device recompute the first spec_rows
+ * flagged rows while the host waits for that count (worth it only when the previous batch had flagged rows; <= 1024).
+ * qsae_prefilter_submit / _finish below are the same call without the round trip inside. */
 size_t qsae_prefilter_w_bytes(int H, int D);
 int qsae_prefilter_pack_w(const float* W, const float* bias, int H, int D, void* Wq, float* meta,
                           qsae_stream_t stream);
@@ -127,7 +147,7 @@ size_t qsae_encode_topk_prefilter_workspace_bytes(int B, int D, int H, int k);
 int qsae_encode_topk_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
                                const float* meta, int B, int D, int H, int k, int32_t* idx, float* val,
                                float* dense, int64_t dense_ld, void* workspace, size_t workspace_bytes,
-                               qsae_stream_t stream);
+                               int spec_rows, int* flagged_rows, qsae_stream_t stream);
 
 /* BinarySAE.forward in one call (sae/binary.py:91-103 with binary_decoder.forward, :24-47, on the k kept entries):
  * qsae_encode_topk_prefilter followed by qsae_decode_binary_sparse, with the decode of a row done by the refinement
@@ -139,7 +159,29 @@ int qsae_binary_forward_prefilter(const float* x, const float* W, const float* b
                                   const float* meta, int B, int D, int H, int k, const uint8_t* packed, int n_bits,
                                   float step, const float* dec_bias, int32_t* idx, float* val, float* dense,
                                   int64_t dense_ld, float* recon, void* workspace, size_t workspace_bytes,
-                                  qsae_stream_t stream);
+                                  int spec_rows, int* flagged_rows, qsae_stream_t stream);
+
+/* The same pipeline in two calls, so that the host never waits inside the library and can queue the next batch behind
+ * this one (the blocking forms above are submit + wait + finish):
+ *   submit : everything up to the refinement; every row that did not need the exact fallback is final afterwards.  The
+ *            number of rows that do need it is copied asynchronously, in stream order, into *flagged_host (a host int,
+ *            page-locked if the copy is to be asynchronous); the caller learns when it has landed from an event it
+ *            records behind the call (or any later synchronisation of `stream`).
+ *   finish : given that number, enqueues the exact fallback for those rows (their idx / val / dense entries and, with a
+ *            dictionary, their reconstruction) and, on the paths whose sweep does not write the zeros, the dense latent.
+ *            Outputs may be consumed once finish has been enqueued.  Same arguments as submit; workspace untouched in
+ *            between (a second batch in flight needs a second workspace).
+ * packed == NULL: no reconstruction (qsae_encode_topk_prefilter), n_bits / step / dec_bias / recon ignored. */
+int qsae_prefilter_submit(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                          int B, int D, int H, int k, const uint8_t* packed, int n_bits, float step,
+                          const float* dec_bias, int32_t* idx, float* val, float* dense, int64_t dense_ld,
+                          float* recon, void* workspace, size_t workspace_bytes, int* flagged_host,
+                          qsae_stream_t stream);
+int qsae_prefilter_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                          int B, int D, int H, int k, const uint8_t* packed, int n_bits, float step,
+                          const float* dec_bias, int32_t* idx, float* val, float* dense, int64_t dense_ld,
+                          float* recon, void* workspace, size_t workspace_bytes, int flagged,
+                          qsae_stream_t stream);
 
 /* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
 int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
@@ -152,9 +194,15 @@ int qsae_binary_row_bytes(int D, int n_bits);
 /* Hard two's-complement packer == binary_decoder.quantized_int_weights(), sae/binary.py:49-58:
  * bit = sigmoid(logit) > 0.5; logits [H][D*n_bits] (column d*n+b = bit b of output d, LSB first,
  * MSB negative) -> packed [H][row_bytes], fields little-endian.  If polarize_sum != NULL the
- * device double receives sum(p(1-p)2^b) (sae/binary.py:42-43; caller divides by H*D*n). */
+ * device double receives sum(p(1-p)2^b) (sae/binary.py:42-43; caller divides by H*D*n).
+ * If soft_gap != NULL the device float receives max over (h, d) of |soft - hard| with
+ * soft = sum_b sigmoid(logit_b) bw_b -- the integer the reference's forward actually multiplies
+ * with (sae/binary.py:26-35) -- and hard the packed integer: the distance, in integer steps,
+ * between the reference forward and a hard-bit decode of this checkpoint (~1e-12 at +-30
+ * logits, ~0.5 for an untrained decoder; +inf for NaN logits).  The host side uses it to pick
+ * qsae_decode_binary_sparse (hard) or qsae_decode_table_sparse over qsae_binary_soft_table. */
 int qsae_pack_binary(const float* logits, int H, int D, int n_bits, uint8_t* packed,
-                     double* polarize_sum, qsae_stream_t stream);
+                     double* polarize_sum, float* soft_gap, qsae_stream_t stream);
 /* int_weights[h][d] as fp32 (for decoder_dictionary(), inference/framework.py:114-124). */
 int qsae_unpack_binary(const uint8_t* packed, int H, int D, int n_bits, float* int_weights,
                        qsae_stream_t stream);
@@ -206,7 +254,7 @@ int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, int B, int H
  * chain.  Bit-identical to qsae_encode_bits.  Rows with more than 2048 listed latents (dense activations) and
  * rows with non-finite inputs are recomputed by the exact dense kernel; *flagged_rows (host int, may be NULL)
  * receives their count so that a caller can route a dense-regime model to qsae_encode_bits.  D in {128,256,512},
- * H % 64 == 0, else QSAE_ERR_UNSUPPORTED.  One host round trip per call. */
+ * H % 64 == 0, else QSAE_ERR_UNSUPPORTED.  One host round trip per call (that count). */
 size_t qsae_encode_bits_prefilter_workspace_bytes(int B, int D, int H);
 int qsae_encode_bits_prefilter(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
                                int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,

@@ -143,6 +143,28 @@ def polarize(logits, D: int, n_bits: int) -> float:
     return float(lib().qsae_oracle_polarize(_p(logits), C.c_int(logits.shape[0]), C.c_int(D), C.c_int(n_bits)))
 
 
+def soft_table(logits, D: int, n_bits: int) -> np.ndarray:
+    """int_weights of binary_decoder.forward (binary.py:26-35): sum_b sigmoid(logit_b) * bw_b with
+    bw = [1, 2, .., -2^(n-1)], every operation rounded to fp32, bits summed LSB first."""
+    logits = _f32(logits)
+    H = logits.shape[0]
+    assert logits.shape[1] == D * n_bits
+    one = np.float32(1.0)
+    with np.errstate(over="ignore"):
+        p = (one / (one + np.exp(-logits, dtype=np.float32))).astype(np.float32).reshape(H, D, n_bits)
+    acc = np.zeros((H, D), dtype=np.float32)
+    for b in range(n_bits):
+        bw = np.float32(-(1 << b) if b == n_bits - 1 else (1 << b))
+        acc = (acc + (p[:, :, b] * bw).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def soft_gap(logits, D: int, n_bits: int) -> float:
+    """max |soft integer - hard integer| over the dictionary (what qsae_pack_binary reports)."""
+    hard = unpack_binary(pack_binary(logits, D, n_bits), D, n_bits)
+    return float(np.max(np.abs(soft_table(logits, D, n_bits) - hard)))
+
+
 def decode_binary(idx, val, packed, D: int, n_bits: int, step: float, bias=None) -> np.ndarray:
     idx = np.ascontiguousarray(idx, dtype=np.int32)
     val = _f32(val)
@@ -235,17 +257,24 @@ def sq_err_sum(recon, x) -> float:
 # ---------------------------------------------------------------------------
 # Whole-forward restatements (compose the primitives exactly as the reference does)
 
-def binary_forward(x, enc_w, enc_b, dec_logits, dec_bias, *, n_bits: int, gamma: float, k: int = None):
-    """BinarySAE.forward with hard bits (binary.py:91-103 + 49-58).
+def binary_forward(x, enc_w, enc_b, dec_logits, dec_bias, *, n_bits: int, gamma: float, k: int = None,
+                   soft: bool = False):
+    """BinarySAE.forward (binary.py:91-103).  soft=False: the hard two's-complement integers of
+    quantized_int_weights() (binary.py:49-58) -- what the forward converges to on a polarised checkpoint;
+    soft=True: the sigmoid-bit integers the reference forward multiplies with (binary.py:26-38), evaluated on the k
+    kept entries in ascending index order.
     Returns dict(idx, val, latent(dense), reconstruction, polarize_loss)."""
     H, D = np.asarray(enc_w).shape
     if k is None:
         k = int(H * 0.002)
     latent = encode(x, enc_w, enc_b, ACT_NONE)
     idx, val = topk(latent, k)
-    packed = pack_binary(dec_logits, D, n_bits)
     step = np.float32(gamma / (2 ** (n_bits - 1)))
-    recon = decode_binary(idx, val, packed, D, n_bits, float(step), dec_bias)
+    if soft:
+        recon = decode_table(idx, val, soft_table(dec_logits, D, n_bits), float(step), dec_bias)
+    else:
+        packed = pack_binary(dec_logits, D, n_bits)
+        recon = decode_binary(idx, val, packed, D, n_bits, float(step), dec_bias)
     return {"idx": idx, "val": val, "latent_full": latent, "latent": densify(idx, val, H),
             "reconstruction": recon, "polarize_loss": polarize(dec_logits, D, n_bits)}
 

@@ -14,6 +14,10 @@ import os
 
 # QSAE_HIP_LIB: another build of the same library (same-box A/B timing of two builds); default: the in-tree one
 LIB_PATH = Path(os.environ["QSAE_HIP_LIB"]) if os.environ.get("QSAE_HIP_LIB") else _PKG / "lib" / "libqsae_hip.so"
+# The debug build (same sources + -DQSAE_DEBUG_BUILD): process-wide qsae_debug_* switches and ablation kernels.  Never
+# loaded by the package itself; tools/ and a few tests ask for it explicitly (use_library("debug")).
+DEBUG_LIB_PATH = _PKG / "lib" / "libqsae_hip_debug.so"
+ABI_VERSION = 2
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
@@ -26,6 +30,8 @@ SIGNATURES = {
     "qsae_abi_version": (_i, []),
     "qsae_last_error": (C.c_char_p, []),
     "qsae_device_info": (_i, [C.POINTER(_i), C.c_char_p, _i]),
+    "qsae_profile_sweep_events": (_i, [_vp, _vp]),
+    "qsae_profile_sweep_flop_fraction": (C.c_double, [_i]),
     "qsae_kperm_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "qsae_encode_dense": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_encode_dense_kperm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
@@ -38,12 +44,17 @@ SIGNATURES = {
     "qsae_prefilter_w_bytes": (_sz, [_i, _i]),
     "qsae_prefilter_pack_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "qsae_encode_topk_prefilter_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "qsae_encode_topk_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "qsae_encode_topk_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _sz, _i,
+                                         C.POINTER(_i), _vp]),
     "qsae_binary_forward_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i64, _vp,
-                                            _vp, _sz, _vp]),
+                                            _vp, _sz, _i, C.POINTER(_i), _vp]),
+    "qsae_prefilter_submit": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i64, _vp,
+                                    _vp, _sz, _vp, _vp]),
+    "qsae_prefilter_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i64, _vp,
+                                    _vp, _sz, _i, _vp]),
     "qsae_densify": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_binary_row_bytes": (_i, [_i, _i]),
-    "qsae_pack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "qsae_pack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "qsae_unpack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "qsae_decode_binary_sparse": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "qsae_decode_table_sparse": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp]),
@@ -74,27 +85,52 @@ class QsaeError(RuntimeError):
         self.code = code
 
 
-_lib: Optional[C.CDLL] = None
+_libs = {}          # "product" / "debug" -> CDLL
+_active = "product"
 
 
-def load() -> C.CDLL:
-    """Load libqsae_hip.so (once).  Raises RuntimeError if it is missing -- no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.exists():
+def _open(path: Path) -> C.CDLL:
+    if not path.exists():
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m quantizedsae_amd.build` "
+            f"{path} is missing: build it with `python -m quantizedsae_amd.build` "
             "(hipcc --offload-arch=gfx950).  quantizedsae_amd has no CPU / eager fallback.")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here means the library is stale
         fn.restype = res
         fn.argtypes = args
-    if lib.qsae_abi_version() != 1:
-        raise RuntimeError("libqsae_hip.so ABI version mismatch; rebuild it")
-    _lib = lib
+    if lib.qsae_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path.name}: ABI version mismatch; rebuild it")
     return lib
+
+
+def load() -> C.CDLL:
+    """The library the package computes with: libqsae_hip.so (loaded once).  Raises RuntimeError if it is missing --
+    no fallback.  Inside a `use_library("debug")` block (tests / tools only) it is the debug build instead."""
+    lib = _libs.get(_active)
+    if lib is None:
+        lib = _libs[_active] = _open(LIB_PATH if _active == "product" else DEBUG_LIB_PATH)
+    return lib
+
+
+class use_library:
+    """Context manager for tests and tools: route the package's calls to the debug build (qsae_debug_* switches,
+    ablation kernels) for the duration of the block.  Not thread-safe, not for product code."""
+
+    def __init__(self, which: str):
+        if which not in ("product", "debug"):
+            raise ValueError(which)
+        self.which = which
+
+    def __enter__(self):
+        global _active
+        self.prev, _active = _active, self.which
+        return load()
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self.prev
+        return False
 
 
 def check(code: int) -> None:

@@ -13,12 +13,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- packer -----------------------------------------------------------------------------
 // One thread per output dword: 32/fw fields, each from n_bits logits.
+// soft_gap (optional): max over all (h, d) of |soft - hard|, soft = sum_b sigmoid(logit_b) bw_b (what the reference's
+// forward multiplies with, sae/binary.py:26-35), hard = the packed two's-complement integer (sae/binary.py:49-58).
+// It is how far the reference forward is from a hard-bit decode of this checkpoint, in units of one integer step:
+// ~1e-12 for +-30 logits, 0.5 for logits near 0.  NaN logits give +inf.
 __global__ void __launch_bounds__(256)
 pack_binary_kernel(const float* __restrict__ logits, int H, int D, int n, int fw, int row_dwords,
-                   uint32_t* __restrict__ packed, double* __restrict__ polarize_sum) {
+                   uint32_t* __restrict__ packed, double* __restrict__ polarize_sum, unsigned* __restrict__ soft_gap) {
     const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     const long long total = static_cast<long long>(H) * row_dwords;
     double psum = 0.0;
+    float gap = 0.0f;
+    const bool stats = polarize_sum != nullptr || soft_gap != nullptr;
     if (gid < total) {
         const int h = static_cast<int>(gid / row_dwords), c = static_cast<int>(gid % row_dwords);
         const int F = 32 / fw;
@@ -28,22 +34,35 @@ pack_binary_kernel(const float* __restrict__ logits, int H, int D, int n, int fw
             const int d = c * F + f;
             if (d >= D) break;
             uint32_t code = 0;
+            float soft = 0.0f;
             for (int b = 0; b < n; ++b) {
                 const float w = lrow[d * n + b];
                 code |= (sig_gt_half(w) ? 1u : 0u) << b;
-                if (polarize_sum) {
+                if (stats) {
                     const float p = 1.0f / (1.0f + expf(-w));
                     psum += static_cast<double>(p * (1.0f - p) * static_cast<float>(1u << b));
+                    soft = soft + p * ((b == n - 1) ? -static_cast<float>(1u << b) : static_cast<float>(1u << b));
                 }
+            }
+            if (stats) {
+                const float hard = static_cast<float>(sbfe_i32(static_cast<int>(code), 0, n));
+                const float g = fabsf(soft - hard);
+                gap = (g > gap || g != g) ? (g != g ? __builtin_huge_valf() : g) : gap;
             }
             word |= code << (f * fw);
         }
         packed[gid] = word;
     }
-    if (polarize_sum) {
+    if (stats) {
         // wave reduce, then one atomic per wave
-        for (int off = 32; off > 0; off >>= 1) psum += __shfl_down(psum, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(polarize_sum, psum);
+        for (int off = 32; off > 0; off >>= 1) {
+            psum += __shfl_down(psum, off, 64);
+            gap = fmaxf(gap, __shfl_down(gap, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (polarize_sum) atomicAdd(polarize_sum, psum);
+            if (soft_gap) atomicMax(soft_gap, __float_as_uint(gap));    // non-negative floats order like their bit patterns
+        }
     }
 }
 
@@ -191,7 +210,7 @@ extern "C" int qsae_binary_row_bytes(int D, int n_bits) {
 }
 
 extern "C" int qsae_pack_binary(const float* logits, int H, int D, int n_bits, uint8_t* packed,
-                                double* polarize_sum, qsae_stream_t stream) {
+                                double* polarize_sum, float* soft_gap, qsae_stream_t stream) {
     QSAE_CHECK_ARG(H > 0 && D > 0, "H > 0 and D > 0 required");
     QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= 8, "1 <= n_bits <= 8 required");
     QSAE_CHECK_ARG(logits && packed, "null pointer");
@@ -200,8 +219,10 @@ extern "C" int qsae_pack_binary(const float* logits, int H, int D, int n_bits, u
     const long long total = static_cast<long long>(H) * row_dwords;
     hipStream_t s = as_stream(stream);
     if (polarize_sum) QSAE_HIP(hipMemsetAsync(polarize_sum, 0, sizeof(double), s));
+    if (soft_gap) QSAE_HIP(hipMemsetAsync(soft_gap, 0, sizeof(float), s));
     hipLaunchKernelGGL(pack_binary_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, logits,
-                       H, D, n_bits, fw, row_dwords, reinterpret_cast<uint32_t*>(packed), polarize_sum);
+                       H, D, n_bits, fw, row_dwords, reinterpret_cast<uint32_t*>(packed), polarize_sum,
+                       reinterpret_cast<unsigned*>(soft_gap));
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }

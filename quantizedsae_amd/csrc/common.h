@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/qsae.h"
 
 namespace qsae {
@@ -42,6 +44,58 @@ inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, 
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline hipStream_t as_stream(qsae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- host-side state ------------------------------------------------------------------
+// The library keeps no state that one call hands to another.  What it does keep is (a) "this kernel's dynamic-LDS
+// limit has been raised on device d" -- a per-device fact (hipFuncSetAttribute acts on the current device's copy of
+// the code object), set once per device and instantiation -- and (b) helper objects (side stream, events, a pinned
+// word) owned by one host thread for one device (ThreadDeviceCtx below), so that two host threads, or one thread
+// walking over several devices, never share them.  Callers make the device of their pointers current, as for any HIP
+// library; the current device is what keys both tables.
+constexpr int kMaxDevices = 64;
+
+struct PerDeviceOnce {
+    std::atomic<unsigned char> done[kMaxDevices];
+};
+
+// Runs f() (a HIP attribute call returning hipError_t) once per device; two threads racing on the same device both
+// run it, which is harmless (the call is idempotent).
+template <class F>
+inline hipError_t once_per_device(PerDeviceOnce& o, F&& f) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    if (tracked && o.done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = f();
+    if (e == hipSuccess && tracked) o.done[dev].store(1, std::memory_order_release);
+    return e;
+}
+
+#define QSAE_SET_MAX_LDS_ONCE(kern, bytes)                                                        \
+    do {                                                                                          \
+        static ::qsae::PerDeviceOnce once_;                                                       \
+        QSAE_HIP(::qsae::once_per_device(once_, [&]() {                                           \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)); \
+        }));                                                                                      \
+    } while (0)
+
+// Helper objects of the calling host thread on the current device (created on first use, never shared):
+//   side, ev_fork, ev_join : the stream the co-resident zero-fill kernel runs on, forked from / joined into the caller's
+//   pinned, ev_copied      : page-locked word + event for the one 4-byte read-back of the blocking entry points
+//   prof_begin / prof_end  : one-shot profiling events (qsae_profile_sweep_events)
+struct ThreadDeviceCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_copied = nullptr;
+    int* pinned = nullptr;
+};
+int thread_device_ctx(ThreadDeviceCtx** out);     // misc.hip; QSAE_OK or an error code
+
+struct SweepProfile {
+    hipEvent_t begin = nullptr, end = nullptr;
+};
+SweepProfile take_sweep_profile();                // misc.hip: the calling thread's one-shot event pair (then cleared)
 
 // ---- device helpers -----------------------------------------------------------------
 // fp32 cutoffs of the reference's sigmoid (see oracle/qsae_oracle.c header):

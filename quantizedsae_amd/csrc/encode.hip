@@ -10,9 +10,11 @@
 
 namespace qsae {
 
-static int g_gemm_config = 0;   // kept for the debug ABI; only one tile shape is built
+// tuning switches: variables (behind qsae_debug_* setters) in the debug library only, constants in the product library
+#ifdef QSAE_DEBUG_BUILD
 int g_sweep_override = 0;       // 0 = heuristic (pick_sweep)
 int g_stagger = 0;              // start delay of the second co-resident block, x1024 cycles
+#endif
 
 // ---- epilogues ------------------------------------------------------------------------
 template <int MT, int NT, int WTM, int WTN>
@@ -164,10 +166,8 @@ static int dispatch_dense(const float* x, const float* W, const float* bias, int
 
 using namespace qsae;
 
-extern "C" int qsae_debug_set_gemm_config(int cfg) {
-    g_gemm_config = cfg;
-    return QSAE_OK;
-}
+#ifdef QSAE_DEBUG_BUILD
+extern "C" int qsae_debug_set_gemm_config(int) { return QSAE_OK; }   // one tile shape is built; kept for old tools
 
 // Diagnosis only: the encoder contraction with parts of the pipeline removed (results are wrong).
 extern "C" int qsae_debug_encode_ablate(const float* x, const float* W, int B, int D, int H, float* out, int cfg,
@@ -200,6 +200,7 @@ extern "C" int qsae_debug_set_sweep(int sweep) {
     g_sweep_override = sweep;
     return QSAE_OK;
 }
+#endif  // QSAE_DEBUG_BUILD
 
 static int encode_dense_impl(const float* x, const float* W, const float* bias, int B, int D, int H, int act,
                              float* out, int64_t out_ld, qsae_stream_t stream, bool kperm) {

@@ -37,34 +37,40 @@ int densify_rows(const int32_t* idx, const float* val, int B, int k, int H, floa
 
 constexpr int kChunkRows = 1024;   // chunked form: 1024 x 32768 x 4 B = 128 MiB of latent per chunk
 constexpr int kCandCap = 1024;     // candidate slots per row
-static int kPilotRank = 20;        // tau = kPilotRank-th largest pilot value (debug-tunable together with the pilot width)
-static int g_pilot_div = 16;       // pilot block = H / g_pilot_div hidden units
 constexpr int kFusedMinRows = 2048;
 constexpr int kFusedMinHidden = 8192;
-static int g_force_path = 0;       // 0 auto, 1 chunked, 2 fused (debug/testing)
-static int g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
-static unsigned long long* g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
-static int g_fuse_xprep = 0;       // 1: the stationary sweep scales / converts the activations in its prologue (no gain
-                                   // measured: the prologue costs what the 0.07 ms preparation launch saves)
-static int g_inkernel_pilot = 1;   // the stationary sweep derives tau itself (no pilot GEMM / selection launches)
-static int g_inkernel_rank = 0;    // tau = this rank among the row's 32 group maxima; 0 = from k (inkernel_rank)
-static int g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
-static int g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
-static int g_fill_co = 1;          // zeros from a co-resident fill kernel on a second stream (0: inside the sweep; > 1: that many fill waves)
 constexpr int kFillCoWaves = 1024; // fill waves beside the sweep: one per SIMD, so every sweep wave has the same neighbour
 constexpr int kFillCoPace = 4;     // s_sleep(1) per store: the fill ends with the sweep (measured scan in the kernel's comment)
-static int g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
-static unsigned long long* g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
-static int g_ref_ablate = 0;        // timing experiments on the refine kernel (results wrong when non-zero)
-static int g_last_flagged = 0;      // rows the last fused / prefilter call sent through the exact fallback
-static int g_xstat_ablate = 0;     // timing experiments only (results are wrong when non-zero)
-static int g_pref_tile = 2;        // fp16 sweep: 2 = activation-stationary kernel (where supported), 0 = 256 x 256 tile
-                                   // (2 stages), 1 = 256 x 128 tile (3 stages)
 
-// Optional HIP-event bracket around the sweep kernel (bench.py's live roofline measurement): events
-// are recorded on the launch stream and only read by qsae_debug_sweep_timing_collect().
-static bool g_time_sweep = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_sweep_events;
+// Tuning / ablation switches.  The product library (libqsae_hip.so) is built without QSAE_DEBUG_BUILD: every switch is
+// a compile-time constant there, no qsae_debug_* symbol exists and no ablation kernel is instantiated.  The debug
+// library (libqsae_hip_debug.so, same sources with -DQSAE_DEBUG_BUILD; used by tools/ and by the tests that need to
+// force a path on a small shape) makes them process-wide variables behind the qsae_debug_* setters.
+#ifdef QSAE_DEBUG_BUILD
+#define QSAE_TUNABLE static int
+#define QSAE_TUNABLE_PTR static unsigned long long*
+#else
+#define QSAE_TUNABLE static constexpr int
+#define QSAE_TUNABLE_PTR static constexpr unsigned long long*
+#endif
+QSAE_TUNABLE kPilotRank = 20;        // tau = kPilotRank-th largest pilot value (together with the pilot width)
+QSAE_TUNABLE g_pilot_div = 16;       // pilot block = H / g_pilot_div hidden units
+QSAE_TUNABLE g_force_path = 0;       // 0 auto, 1 chunked, 2 fused
+QSAE_TUNABLE g_sweep_kernel = 0;     // K-interleaved operands: 0 = LDS-DMA sweep kernel, 1 = register-staged one
+QSAE_TUNABLE_PTR g_xstat_stamps = nullptr;   // device buffer for the phase stamps (ablation 5)
+QSAE_TUNABLE g_fuse_xprep = 0;       // 1: the stationary sweep scales / converts the activations in its prologue (no gain
+                                     // measured: the prologue costs what the 0.07 ms preparation launch saves)
+QSAE_TUNABLE g_inkernel_pilot = 1;   // the stationary sweep derives tau itself (no pilot GEMM / selection launches)
+QSAE_TUNABLE g_inkernel_rank = 0;    // tau = this rank among the row's 32 group maxima; 0 = from k (inkernel_rank)
+QSAE_TUNABLE g_pilot_tile = 0;       // fp16 pilot GEMM tile: 0 = 256 x 256 (2 stages), 1 = 256 x 128 (3 stages)
+QSAE_TUNABLE g_fill_in_sweep = 1;    // zero-fill of the dense latent inside the activation-stationary sweep
+QSAE_TUNABLE g_fill_co = 1;          // zeros from a co-resident fill kernel on a second stream (0: inside the sweep; > 1: that many fill waves)
+QSAE_TUNABLE g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
+QSAE_TUNABLE_PTR g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
+QSAE_TUNABLE g_ref_ablate = 0;       // timing experiments on the refine kernel (results wrong when non-zero)
+QSAE_TUNABLE g_xstat_ablate = 0;     // timing experiments only (results are wrong when non-zero)
+QSAE_TUNABLE g_pref_tile = 2;        // fp16 sweep: 2 = activation-stationary kernel (where supported), 0 = 256 x 256 tile
+                                     // (2 stages), 1 = 256 x 128 tile (3 stages)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -307,7 +313,7 @@ select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
 }
 
 // ---- fallback helpers ---------------------------------------------------------------------------
-static int kSpecRows = 32;         // flagged rows the fallback handles before the host knows their count (debug-tunable; 0 = wait for the count first)
+constexpr int kMaxSpecRows = kChunkRows;   // upper bound of the caller's spec_rows (one fallback chunk)
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, int n, int D, float* __restrict__ dst) {
     const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -374,72 +380,97 @@ static int run_chunked(const float* x, const float* W, const float* bias, int B,
     return QSAE_OK;
 }
 
-// Flagged rows (tau not a valid lower bound, overflowing list, non-finite inputs): normally none.  One
-// 4-byte read-back, then the unfused exact kernels on exactly those rows.
-static int run_flagged_rows(const float* x, const float* W, const float* bias, int B, int D, int H, int k,
-                            int32_t* idx, float* val, char* ws, const FusedLayout& L, qsae_stream_t stream,
-                            bool kperm, float* dense = nullptr, int64_t dense_ld = 0) {
-    hipStream_t s = as_stream(stream);
-    int* flags = reinterpret_cast<int*>(ws + L.flags);
-    float* fx = reinterpret_cast<float*>(ws + L.fx);
-    float* flat = reinterpret_cast<float*>(ws + L.flat);
-    int32_t* fidx = reinterpret_cast<int32_t*>(ws + L.fidx);
-    float* fval = reinterpret_cast<float*>(ws + L.fval);
-    // The flagged-row count comes back through a pinned word (one per host thread, allocated on first use; a pageable
-    // destination makes the runtime stage the copy).  The host waits for THAT COPY only (an event right behind it),
-    // and meanwhile the GPU already runs the exact fallback for the first kSpecRows flagged rows with the count read
-    // on the device: a typical batch has a handful of flagged rows, so the device never idles through the host round
-    // trip and the caller's next launches queue up behind work that is still running.
-    static thread_local int* pinned = nullptr;
-    static thread_local hipEvent_t copied = nullptr;
-    if (!pinned) QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
-    if (!copied) QSAE_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
-    *pinned = 0;
-    QSAE_HIP(hipMemcpyAsync(pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    QSAE_HIP(hipEventRecord(copied, s));
-    // Speculate only when the previous call had flagged rows: with nine record slots per lane most batches have none,
-    // and then the 32-row exact pass (0.09 ms) costs more than the host round trip it hides (0.03 ms).
-    const int spec = g_last_flagged > 0 ? (B < kSpecRows ? B : kSpecRows) : 0;
-    if (spec > 0) {
-        const long long tot = static_cast<long long>(spec) * D;
-        hipLaunchKernelGGL(gather_rows_dev_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x,
-                           flags + 1, flags, spec, D, fx);
-        QSAE_LAUNCH_CHECK();
-        int rc = dense_latent(fx, W, bias, spec, D, H, flat, H, stream, kperm);
-        if (rc != QSAE_OK) return rc;
-        rc = qsae_topk_rows(flat, H, spec, H, k, fidx, fval, 0, stream);
-        if (rc != QSAE_OK) return rc;
-        const long long tk = static_cast<long long>(spec) * k;
-        hipLaunchKernelGGL(scatter_topk_dev_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx,
-                           fval, flags + 1, flags, spec, k, idx, val, dense, dense_ld, H);
-        QSAE_LAUNCH_CHECK();
-    }
-    QSAE_HIP(hipEventSynchronize(copied));
-    const int nflag = *pinned;
-    g_last_flagged = nflag;
-    if (nflag <= spec) return QSAE_OK;
-    for (int f0 = spec; f0 < nflag; f0 += kChunkRows) {
+// Flagged rows (tau not a valid lower bound, overflowing list, non-finite inputs): normally none.  They are
+// recomputed by the unfused exact kernels.  Their number lives in device memory (flags[0], the row ids behind it); the
+// host needs it to size those launches.  Three pieces, so that the caller decides where the one 4-byte read-back goes:
+//   * flagged_spec  : the exact fallback for the first `spec` flagged rows with the count read ON THE DEVICE -- enqueued
+//                     before the host knows the count (unused slots recompute ordinary rows into scratch);
+//   * flagged_range : the exact fallback for flagged rows [first, nflag), count known to the host;
+//   * the blocking entry points copy the count into the calling thread's pinned word, wait for THAT COPY only (an event
+//     right behind it) and call flagged_range; the submit / finish pair hands the word to the caller instead.
+struct FlaggedArgs {
+    const float* x; const float* W; const float* bias;
+    int B, D, H, k;
+    int32_t* idx; float* val;
+    char* ws; FusedLayout L;
+    qsae_stream_t stream; bool kperm;
+    float* dense; int64_t dense_ld;      // optional already zero-filled dense latent: the rows' entries are written into it
+};
+
+static int flagged_spec(const FlaggedArgs& a, int spec) {
+    if (spec <= 0) return QSAE_OK;
+    hipStream_t s = as_stream(a.stream);
+    int* flags = reinterpret_cast<int*>(a.ws + a.L.flags);
+    float* fx = reinterpret_cast<float*>(a.ws + a.L.fx);
+    float* flat = reinterpret_cast<float*>(a.ws + a.L.flat);
+    int32_t* fidx = reinterpret_cast<int32_t*>(a.ws + a.L.fidx);
+    float* fval = reinterpret_cast<float*>(a.ws + a.L.fval);
+    const long long tot = static_cast<long long>(spec) * a.D;
+    hipLaunchKernelGGL(gather_rows_dev_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, a.x,
+                       flags + 1, flags, spec, a.D, fx);
+    QSAE_LAUNCH_CHECK();
+    int rc = dense_latent(fx, a.W, a.bias, spec, a.D, a.H, flat, a.H, a.stream, a.kperm);
+    if (rc != QSAE_OK) return rc;
+    rc = qsae_topk_rows(flat, a.H, spec, a.H, a.k, fidx, fval, 0, a.stream);
+    if (rc != QSAE_OK) return rc;
+    const long long tk = static_cast<long long>(spec) * a.k;
+    hipLaunchKernelGGL(scatter_topk_dev_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx,
+                       fval, flags + 1, flags, spec, a.k, a.idx, a.val, a.dense, a.dense_ld, a.H);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+static int flagged_range(const FlaggedArgs& a, int first, int nflag) {
+    hipStream_t s = as_stream(a.stream);
+    int* flags = reinterpret_cast<int*>(a.ws + a.L.flags);
+    float* fx = reinterpret_cast<float*>(a.ws + a.L.fx);
+    float* flat = reinterpret_cast<float*>(a.ws + a.L.flat);
+    int32_t* fidx = reinterpret_cast<int32_t*>(a.ws + a.L.fidx);
+    float* fval = reinterpret_cast<float*>(a.ws + a.L.fval);
+    for (int f0 = first; f0 < nflag; f0 += kChunkRows) {
         const int n = (nflag - f0) < kChunkRows ? (nflag - f0) : kChunkRows;
         const int* rows = flags + 1 + f0;
-        const long long tot = static_cast<long long>(n) * D;
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows, n,
-                           D, fx);
+        const long long tot = static_cast<long long>(n) * a.D;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, a.x, rows, n,
+                           a.D, fx);
         QSAE_LAUNCH_CHECK();
-        int rc = dense_latent(fx, W, bias, n, D, H, flat, H, stream, kperm);
+        int rc = dense_latent(fx, a.W, a.bias, n, a.D, a.H, flat, a.H, a.stream, a.kperm);
         if (rc != QSAE_OK) return rc;
-        rc = qsae_topk_rows(flat, H, n, H, k, fidx, fval, 0, stream);
+        rc = qsae_topk_rows(flat, a.H, n, a.H, a.k, fidx, fval, 0, a.stream);
         if (rc != QSAE_OK) return rc;
-        const long long tk = static_cast<long long>(n) * k;
+        const long long tk = static_cast<long long>(n) * a.k;
         hipLaunchKernelGGL(scatter_topk_kernel, dim3(static_cast<unsigned>((tk + 255) / 256)), dim3(256), 0, s, fidx, fval,
-                           rows, n, k, idx, val, dense, dense_ld, H);
+                           rows, n, a.k, a.idx, a.val, a.dense, a.dense_ld, a.H);
         QSAE_LAUNCH_CHECK();
     }
     return QSAE_OK;
 }
 
+// Blocking form: count -> this thread's pinned word, wait for that copy, exact fallback.  *nflag_out = the count.
+static int flagged_blocking(const FlaggedArgs& a, int spec, int* nflag_out) {
+    hipStream_t s = as_stream(a.stream);
+    const int* flags = reinterpret_cast<const int*>(a.ws + a.L.flags);
+    ThreadDeviceCtx* ctx = nullptr;
+    int rc = thread_device_ctx(&ctx);
+    if (rc != QSAE_OK) return rc;
+    *ctx->pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(ctx->pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipEventRecord(ctx->ev_copied, s));
+    spec = spec < 0 ? 0 : (spec > kMaxSpecRows ? kMaxSpecRows : spec);
+    spec = spec < a.B ? spec : a.B;
+    rc = flagged_spec(a, spec);          // the device works on these while the host waits for the count
+    if (rc != QSAE_OK) return rc;
+    QSAE_HIP(hipEventSynchronize(ctx->ev_copied));
+    const int nflag = *ctx->pinned;
+    if (nflag_out) *nflag_out = nflag;
+    if (nflag < 0 || nflag > a.B) return fail(QSAE_ERR_HIP, "%s: corrupt flagged-row count", __func__);
+    return flagged_range(a, spec, nflag);
+}
+
 static int run_fused(const float* x, const float* W, const float* bias, int B, int D, int H, int k, int32_t* idx,
                      float* val, char* ws, qsae_stream_t stream, bool kperm, float* dense, int64_t dense_ld) {
     hipStream_t s = as_stream(stream);
+    const SweepProfile prof = take_sweep_profile();
     const FusedLayout L = fused_layout(B, D, H, k);
     const int P = pilot_width(H);
     float* pilot = reinterpret_cast<float*>(ws + L.pilot);
@@ -461,12 +492,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
         using Epi = EpiFilter<BM, BN>;
         typename Epi::Args ea{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, nullptr, nullptr};
         const int Hs = H - P;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_time_sweep) {
-            QSAE_HIP(hipEventCreate(&e0));
-            QSAE_HIP(hipEventCreate(&e1));
-            QSAE_HIP(hipEventRecord(e0, s));
-        }
+        if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
         if (kperm && g_sweep_kernel == 0 && D % kDmaBK == 0) {
             using EpiD = EpiFilter<256, 128, 4, 2>;
             typename EpiD::Args ed{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, nullptr, nullptr};
@@ -490,10 +516,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
             typename LB::Args lb{x, D, B};
             rc = launch_gemm<LA, LB, Epi, BM, BN, BK>(la, lb, ea, Hs, B, D, /*sweep=*/0, s);
         }
-        if (g_time_sweep) {
-            QSAE_HIP(hipEventRecord(e1, s));
-            g_sweep_events.emplace_back(e0, e1);
-        }
+        if (prof.end) QSAE_HIP(hipEventRecord(prof.end, s));
         if (rc != QSAE_OK) return rc;
     }
     // 3. exact selection among the candidates
@@ -501,7 +524,8 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
                        kCandCap, B, H, k, idx, val, flags);
     QSAE_LAUNCH_CHECK();
     // 4. flagged rows (normally none): one 4-byte read-back, then the unfused kernels on those rows
-    rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, kperm);
+    const FlaggedArgs fa{x, W, bias, B, D, H, k, idx, val, ws, L, stream, kperm, nullptr, 0};
+    rc = flagged_blocking(fa, /*spec=*/0, nullptr);
     if (rc != QSAE_OK) return rc;
     if (dense) return scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
     return QSAE_OK;
@@ -986,13 +1010,58 @@ static int inkernel_rank(int k) {
     return r < 6 ? 6 : (r > 24 ? 24 : r);
 }
 
-static int run_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
-                         int B, int D, int H, int k, int32_t* idx, float* val, char* ws, qsae_stream_t stream,
-                         float* dense, int64_t dense_ld, const RowDecode* dec = nullptr) {
-    hipStream_t s = as_stream(stream);
-    const FusedLayout L = fused_layout(B, D, H, k);
-    const PrefLayout PL = pref_layout(B, D, L.total);
-    const int P = pilot_width(H);
+// One prefilter call: the arguments of the entry point plus what follows from them and from the build's switches.
+struct PrefCall {
+    const float* x; const float* W; const float* bias; const _Float16* Wq; const float* meta;
+    int B, D, H, k;
+    int32_t* idx; float* val;
+    char* ws; qsae_stream_t stream;
+    float* dense; int64_t dense_ld;
+    const RowDecode* dec;                 // BinarySAE: rows are decoded as they are ranked; nullptr = no reconstruction
+};
+struct PrefPlan {
+    FusedLayout L; PrefLayout PL;
+    int P;                                // pilot width
+    bool xstat, inkernel, fill_co, fill_in_sweep;
+    int Hs, hoff, parts, cap_part;
+    float* filled;                        // the dense latent if its zeros are written during the sweep launch, else nullptr
+};
+static PrefPlan pref_plan(const PrefCall& c) {
+    PrefPlan p;
+    p.L = fused_layout(c.B, c.D, c.H, c.k);
+    p.PL = pref_layout(c.B, c.D, p.L.total);
+    p.P = pilot_width(c.H);
+    // With the activation-stationary sweep nothing upstream touches the dense latent: its zeros are written during the
+    // sweep launch (co-resident fill kernel, or the sweep's own waves) and the survivors by the refinement; without
+    // either fill it is written once at the end (zeros + the k survivors of every row in one pass, densify_rows).  The
+    // LDS-tiled sweep kernels zero-fill their own blocks in the epilogue and the survivors are scattered in afterwards.
+    p.xstat = g_pref_tile == 2 && xstat_supported(c.D, c.H - p.P, p.P) && c.H % 4 == 0;
+    // In-kernel pilot: the stationary sweep derives tau itself from a stratified H/16 sample of the hidden units (group
+    // maxima, see sweep_xstat_f16.h) and then sweeps ALL hidden units; no pilot GEMM, no pilot buffer, no seeds.
+    p.inkernel = p.xstat && g_inkernel_pilot && p.P % kXsHT == 0 && c.H % kXsHT == 0 && xstat_supported(c.D, c.H, 0);
+    p.Hs = p.inkernel ? c.H : c.H - p.P;                     // hidden units the sweep launch covers
+    p.hoff = p.inkernel ? 0 : p.P;
+    // small batches: the hidden range of the sweep is split over `parts` workgroup columns, each with its own
+    // segment of every row's candidate list
+    p.parts = p.xstat ? xstat_parts(c.B, p.Hs, kCandCap) : 1;
+    p.cap_part = kCandCap / p.parts;
+    p.fill_co = p.xstat && c.dense && g_fill_co && c.D == 512 && c.H % 256 == 0 && c.dense_ld % 4 == 0 && g_xstat_ablate == 0 &&
+                co_fill_fits();
+    p.fill_in_sweep = !p.fill_co && p.xstat && c.dense && g_fill_in_sweep && c.H % 256 == 0 && c.dense_ld % 4 == 0;
+    p.filled = (p.fill_in_sweep || p.fill_co) ? c.dense : nullptr;
+    return p;
+}
+
+// Steps 1-5: everything up to and including the refinement.  Afterwards flags[0] (device) holds the number of rows that
+// need the exact fallback and flags[1..] their ids; every other row's outputs are final.
+static int prefilter_submit(const PrefCall& c) {
+    hipStream_t s = as_stream(c.stream);
+    const SweepProfile prof = take_sweep_profile();
+    const PrefPlan pl = pref_plan(c);
+    const FusedLayout& L = pl.L;
+    const PrefLayout& PL = pl.PL;
+    const int B = c.B, D = c.D, H = c.H, k = c.k, P = pl.P;
+    char* ws = c.ws;
     float* pilot = reinterpret_cast<float*>(ws + L.pilot);
     float* tau = reinterpret_cast<float*>(ws + L.tau);
     int* cnt = reinterpret_cast<int*>(ws + L.cnt);
@@ -1001,91 +1070,73 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
     _Float16* xq = reinterpret_cast<_Float16*>(ws + PL.xq);
     float* inv = reinterpret_cast<float*>(ws + PL.inv);
     float* margin = reinterpret_cast<float*>(ws + PL.margin);
-    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
-    // With the activation-stationary sweep nothing upstream touches the dense latent: it is written once at
-    // the end (zeros + the k survivors of every row in one pass, densify_rows).  The LDS-tiled sweep kernels
-    // zero-fill their own blocks in the epilogue instead and the survivors are scattered in afterwards.
-    const bool xstat = g_pref_tile == 2 && xstat_supported(D, H - P, P) && H % 4 == 0;
-    float* fused_fill = xstat ? nullptr : dense;
-    // In-kernel pilot: the stationary sweep derives tau itself from the first P hidden units (group maxima, see
-    // sweep_xstat_f16.h) and then sweeps ALL hidden units; no pilot GEMM, no pilot buffer, no seeds.
-    const bool inkernel = xstat && g_inkernel_pilot && P % kXsHT == 0 && H % kXsHT == 0 && xstat_supported(D, H, 0);
-    const int Hs = inkernel ? H : H - P;                     // hidden units the sweep launch covers
-    const int hoff = inkernel ? 0 : P;
-    // small batches: the hidden range of the sweep is split over `parts` workgroup columns, each with its own
-    // segment of every row's candidate list
-    const int parts = xstat ? xstat_parts(B, Hs, kCandCap) : 1;
-    const int cap_part = kCandCap / parts;
     int* cnt_parts = reinterpret_cast<int*>(ws + PL.cnt_parts);
-    // activation-stationary sweep: it also zero-fills the dense latent (all H columns, spread over the iterations
-    // of every part: its share of the sweep stages plus the pilot iterations)
+    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+    const bool xstat = pl.xstat, inkernel = pl.inkernel, fill_co = pl.fill_co, fill_in_sweep = pl.fill_in_sweep;
+    float* fused_fill = xstat ? nullptr : c.dense;
+    const int Hs = pl.Hs, hoff = pl.hoff, parts = pl.parts, cap_part = pl.cap_part;
+    // activation-stationary sweep with its own fill: all H columns, spread over the iterations of every part (its
+    // share of the sweep stages plus the pilot iterations)
     const int xs_iters = xstat ? (Hs / kXsHT) / parts + (inkernel ? P / kXsHT : 0) : 0;
     const int fill_cw = xs_iters > 0 ? (32 * (H / 256) / parts + xs_iters - 1) / xs_iters : 0;   // 1-KiB pieces per wave and iteration
-    const bool fill_co = xstat && dense && g_fill_co && D == 512 && H % 256 == 0 && dense_ld % 4 == 0 && g_xstat_ablate == 0 &&
-                         co_fill_fits();
-    const bool fill_in_sweep = !fill_co && xstat && dense && g_fill_in_sweep && H % 256 == 0 && dense_ld % 4 == 0;
-    static thread_local hipStream_t side = nullptr;
-    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (fill_co && !side) {
-        QSAE_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        QSAE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        QSAE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    ThreadDeviceCtx* ctx = nullptr;
+    if (fill_co) {
+        const int rc0 = thread_device_ctx(&ctx);
+        if (rc0 != QSAE_OK) return rc0;
     }
-    // 1. fp16 copy of the batch + per-row scale and error margin (the stationary sweep with the in-kernel pilot does
+    // 1. fp16 copy of the batch + per-row scale and error margin (the stationary sweep with the in-kernel pilot can do
     //    this in its own prologue, straight into registers)
     const bool fuse_prep = inkernel && g_fuse_xprep;
     if (!fuse_prep) {
-        hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
+        hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, c.x, B, D, c.meta, xq, inv, margin);
         QSAE_LAUNCH_CHECK();
     }
     const int Kw = D / 2;                                    // 4-byte words per fp16 row
     const float* xq_w = reinterpret_cast<const float*>(xq);
-    const float* wq_w = reinterpret_cast<const float*>(Wq);
+    const float* wq_w = reinterpret_cast<const float*>(c.Wq);
     // 2. approximate pilot block [B][P] (activation rows on registers, hidden units on lanes)
     int rc = QSAE_OK;
     if (!inkernel) {
         if (g_pilot_tile == 0 && P % 256 == 0) {
             using EpiP = EpiApproxDense<256, 256, 4, 2>;
-            typename EpiP::Args ep{inv, bias, pilot, P};
+            typename EpiP::Args ep{inv, c.bias, pilot, P};
             rc = launch_gemm_dma<EpiP, 256, 256, true, 2>(xq_w, B, wq_w, P, Kw, ep, s, /*sweep=*/8);
         } else {
             using EpiP = EpiApproxDense<256, 128, 4, 2>;
-            typename EpiP::Args ep{inv, bias, pilot, P};
+            typename EpiP::Args ep{inv, c.bias, pilot, P};
             rc = launch_gemm_dma<EpiP, 256, 128, true>(xq_w, B, wq_w, P, Kw, ep, s, /*sweep=*/8);
         }
         if (rc != QSAE_OK) return rc;
     }
     // 3. tau~ = j-th largest approximate pilot value; seeds = pilot elements >= tau~ - 2 eps
     const int j = kPilotRank < P ? kPilotRank : P;
-    if (!inkernel) rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, cap_part, fused_fill, dense_ld, s,
+    if (!inkernel) rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, cap_part, fused_fill, c.dense_ld, s,
                                 margin, kCandCap);
     if (rc != QSAE_OK) return rc;
     // 4. fp16 sweep of the remaining hidden units with the threshold filter (tau~ - 2 eps)
     {
         using EpiS = EpiFilter<256, 128, 4, 2, true>;
-        typename EpiS::Args es{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, fused_fill, dense_ld, inv, margin};
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_time_sweep) {
-            QSAE_HIP(hipEventCreate(&e0));
-            QSAE_HIP(hipEventCreate(&e1));
-            QSAE_HIP(hipEventRecord(e0, s));
-        }
+        typename EpiS::Args es{c.bias ? c.bias + P : nullptr, tau, cand, cnt, kCandCap, P, fused_fill, c.dense_ld, inv, margin};
+        if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
         if (xstat) {
-            XsArgs xa{xq + 0, Wq + static_cast<size_t>(hoff) * D, bias ? bias + hoff : nullptr, tau, margin, inv, cand, cnt,
-                      B, Hs, kCandCap, hoff, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? dense : nullptr, dense_ld, H,
+            XsArgs xa{xq + 0, c.Wq + static_cast<size_t>(hoff) * D, c.bias ? c.bias + hoff : nullptr, tau, margin, inv, cand, cnt,
+                      B, Hs, kCandCap, hoff, g_xstat_rot, g_xstat_stamps, fill_in_sweep ? c.dense : nullptr, c.dense_ld, H,
                       fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank > 0 ? g_inkernel_rank : inkernel_rank(k), tau,
-                      fuse_prep ? x : nullptr, meta, inv, margin, parts, cnt_parts};
-            if (fill_co) QSAE_HIP(hipEventRecord(ev_fork, s));          // everything before the sweep (x prep, earlier users of `dense`)
+                      fuse_prep ? c.x : nullptr, c.meta, inv, margin, parts, cnt_parts};
+            if (fill_co) QSAE_HIP(hipEventRecord(ctx->ev_fork, s));     // everything before the sweep (x prep, earlier users of `dense`)
             rc = launch_xstat(D, xa, s, fill_co ? 9 : g_xstat_ablate);
             if (fill_co && rc == QSAE_OK) {
-                QSAE_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-                hipLaunchKernelGGL(co_delay_kernel, dim3(1), dim3(64), 0, side, 2000);     // 20 us
+                // The zeros are written by a second kernel beside the sweep, on this thread's side stream for this
+                // device: forked from `s` at ev_fork, joined back at ev_join (both events belong to this thread, and a
+                // thread's calls are issued one after the other, so a later record cannot overtake an earlier wait).
+                QSAE_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+                hipLaunchKernelGGL(co_delay_kernel, dim3(1), dim3(64), 0, ctx->side, 2000);     // 20 us
                 QSAE_LAUNCH_CHECK();
-                hipLaunchKernelGGL(fill_zero_co_kernel, dim3(g_fill_co > 1 ? g_fill_co % 10000 : kFillCoWaves), dim3(64), 0, side, dense,
-                                   static_cast<long long>(dense_ld), B, H / 256, g_fill_co > 1 ? g_fill_co / 10000 : kFillCoPace);
+                hipLaunchKernelGGL(fill_zero_co_kernel, dim3(g_fill_co > 1 ? g_fill_co % 10000 : kFillCoWaves), dim3(64), 0, ctx->side,
+                                   c.dense, static_cast<long long>(c.dense_ld), B, H / 256, g_fill_co > 1 ? g_fill_co / 10000 : kFillCoPace);
                 QSAE_LAUNCH_CHECK();
-                QSAE_HIP(hipEventRecord(ev_join, side));
-                QSAE_HIP(hipStreamWaitEvent(s, ev_join, 0));             // refine writes the survivors into the zeros
+                QSAE_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+                QSAE_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));        // refine writes the survivors into the zeros
             }
         } else if (g_pref_tile != 1) {
             // 256 hidden x 256 activation rows per workgroup: 128 FLOP per staged byte (256 x 128: 85)
@@ -1096,41 +1147,76 @@ static int run_prefilter(const float* x, const float* W, const float* bias, cons
         } else {
             rc = launch_gemm_dma<EpiS, 256, 128, true>(wq_w + static_cast<size_t>(P) * Kw, H - P, xq_w, B, Kw, es, s);
         }
-        if (g_time_sweep) {
-            QSAE_HIP(hipEventRecord(e1, s));
-            g_sweep_events.emplace_back(e0, e1);
-        }
+        if (prof.end) QSAE_HIP(hipEventRecord(prof.end, s));
         if (rc != QSAE_OK) return rc;
         if (xstat && g_xstat_ablate != 0) return QSAE_OK;    // timing experiment: the lists are not trustworthy
     }
-    // 5. survivors -> exact chain -> exact top-k
+    // 5. survivors -> exact chain -> exact top-k (-> the row's reconstruction)
     {
         const size_t lds = ref_lds_per_wave(D) * kRefWaves;
-        static bool configured = false;
-        if (!configured) {
-            QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(refine_topk_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = true;
-        }
+        QSAE_SET_MAX_LDS_ONCE(refine_topk_kernel, 160 * 1024);
         hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
-                           cnt, kCandCap, tau, margin, x, W, bias, B, D, H, k, idx, val, flags, g_ref_ablate, g_ref_stamps,
-                           (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld, parts, cnt_parts,
-                           dec ? *dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr});
+                           cnt, kCandCap, tau, margin, c.x, c.W, c.bias, B, D, H, k, c.idx, c.val, flags, g_ref_ablate, g_ref_stamps,
+                           pl.filled, c.dense_ld, parts, cnt_parts,
+                           c.dec ? *c.dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr});
     }
     QSAE_LAUNCH_CHECK();
-    // 6. flagged rows through the exact unfused kernels
-    // (with the zeros written by the sweep, refine and the fallback write the survivors straight into the latent)
-    rc = run_flagged_rows(x, W, bias, B, D, H, k, idx, val, ws, L, stream, /*kperm=*/false,
-                          (fill_in_sweep || fill_co) ? dense : nullptr, dense_ld);
+    return QSAE_OK;
+}
+
+static FlaggedArgs pref_flagged_args(const PrefCall& c, const PrefPlan& pl) {
+    // (with the zeros written during the sweep launch, refine and the fallback write the survivors straight into the latent)
+    return FlaggedArgs{c.x, c.W, c.bias, c.B, c.D, c.H, c.k, c.idx, c.val, c.ws, pl.L, c.stream, /*kperm=*/false,
+                       pl.filled, c.dense_ld};
+}
+
+// Step 6, with the host knowing the flagged-row count: exact fallback for flagged rows [first, nflag) (rows below
+// `first` were handled by flagged_spec), their reconstruction, and the dense latent where nothing has written it yet.
+static int prefilter_finish(const PrefCall& c, int first, int nflag) {
+    hipStream_t s = as_stream(c.stream);
+    const PrefPlan pl = pref_plan(c);
+    if (pl.xstat && g_xstat_ablate != 0) return QSAE_OK;
+    if (nflag < 0 || nflag > c.B) return fail(QSAE_ERR_INVALID_ARG, "%s: flagged-row count out of range", __func__);
+    int rc = flagged_range(pref_flagged_args(c, pl), first, nflag);
     if (rc != QSAE_OK) return rc;
     // rows the exact kernels ranked: their reconstruction through the stand-alone decode kernel, by row list
-    if (dec && g_last_flagged > 0) {
-        rc = decode_binary_sparse_rows(flags + 1, g_last_flagged, idx, val, k, H, *dec, s);
+    if (c.dec && nflag > 0) {
+        const int* flags = reinterpret_cast<const int*>(c.ws + pl.L.flags);
+        rc = decode_binary_sparse_rows(flags + 1, nflag, c.idx, c.val, c.k, c.H, *c.dec, s);
         if (rc != QSAE_OK) return rc;
     }
-    if (dense && !fill_in_sweep && !fill_co)
-        return xstat ? densify_rows(idx, val, B, k, H, dense, dense_ld, s) : scatter_rows(idx, val, B, k, H, dense, dense_ld, s);
+    if (c.dense && !pl.filled)
+        return pl.xstat ? densify_rows(c.idx, c.val, c.B, c.k, c.H, c.dense, c.dense_ld, s)
+                        : scatter_rows(c.idx, c.val, c.B, c.k, c.H, c.dense, c.dense_ld, s);
     return QSAE_OK;
+}
+
+// Blocking form: submit, one 4-byte read-back (with the first `spec` flagged rows recomputed meanwhile), finish.
+static int run_prefilter(const PrefCall& c, int spec, int* flagged_rows) {
+    int rc = prefilter_submit(c);
+    if (rc != QSAE_OK) return rc;
+    const PrefPlan pl = pref_plan(c);
+    if (pl.xstat && g_xstat_ablate != 0) return QSAE_OK;
+    const FlaggedArgs fa = pref_flagged_args(c, pl);
+    int nflag = 0;
+    hipStream_t s = as_stream(c.stream);
+    {
+        const int* flags = reinterpret_cast<const int*>(c.ws + pl.L.flags);
+        ThreadDeviceCtx* ctx = nullptr;
+        rc = thread_device_ctx(&ctx);
+        if (rc != QSAE_OK) return rc;
+        *ctx->pinned = 0;
+        QSAE_HIP(hipMemcpyAsync(ctx->pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+        QSAE_HIP(hipEventRecord(ctx->ev_copied, s));
+        spec = spec < 0 ? 0 : (spec > kMaxSpecRows ? kMaxSpecRows : spec);
+        spec = spec < c.B ? spec : c.B;
+        rc = flagged_spec(fa, spec);
+        if (rc != QSAE_OK) return rc;
+        QSAE_HIP(hipEventSynchronize(ctx->ev_copied));
+        nflag = *ctx->pinned;
+    }
+    if (flagged_rows) *flagged_rows = nflag;
+    return prefilter_finish(c, spec, nflag);
 }
 
 // ---- threshold bits from the candidate sweep: z = (sigmoid(x W^T + b) > 0.5), exact ---------------------------
@@ -1330,6 +1416,7 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
                               int B, int D, int H, uint32_t* zbits, int64_t words_ld, char* ws, qsae_stream_t stream,
                               int* flagged_rows) {
     hipStream_t s = as_stream(stream);
+    const SweepProfile prof = take_sweep_profile();
     const BitsLayout L = bits_layout(B, D, H);
     float* tau = reinterpret_cast<float*>(ws + L.tau);
     int* cnt = reinterpret_cast<int*>(ws + L.cnt);
@@ -1348,43 +1435,28 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
     hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
     QSAE_LAUNCH_CHECK();
     const int parts = xstat_parts(B, H, kBitsCap);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_time_sweep) {
-        QSAE_HIP(hipEventCreate(&e0));
-        QSAE_HIP(hipEventCreate(&e1));
-        QSAE_HIP(hipEventRecord(e0, s));
-    }
+    if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
     XsArgs xa{xq, Wq, bias, tau, margin, inv, cand, cnt, B, H, kBitsCap, 0, g_xstat_rot, nullptr, nullptr, 0, H, 0, 0, 0,
               nullptr, nullptr, meta, nullptr, nullptr, parts, cnt_parts};
     int rc = launch_xstat(D, xa, s, 0);
-    if (g_time_sweep) {
-        QSAE_HIP(hipEventRecord(e1, s));
-        g_sweep_events.emplace_back(e0, e1);
-    }
+    if (prof.end) QSAE_HIP(hipEventRecord(prof.end, s));
     if (rc != QSAE_OK) return rc;
     {
         const size_t lds = bits_lds_per_wave(H) * kBitsWaves;
-        static bool configured = false;
-        if (!configured) {
-            QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resolve_bits_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            configured = true;
-        }
+        QSAE_SET_MAX_LDS_ONCE(resolve_bits_kernel, 160 * 1024);
         hipLaunchKernelGGL(resolve_bits_kernel, dim3((B + kBitsWaves - 1) / kBitsWaves), dim3(64 * kBitsWaves), lds, s,
                            cand, cnt, kBitsCap, parts, cnt_parts, margin, x, W, bias, B, D, H, zbits, words_ld, flags);
         QSAE_LAUNCH_CHECK();
     }
-    // flagged rows: exact dense kernel on the gathered rows (the count comes back through a pinned word)
-    static thread_local int* pinned = nullptr;
-    static thread_local hipEvent_t copied = nullptr;
-    if (!pinned) QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int), hipHostMallocDefault));
-    if (!copied) QSAE_HIP(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
-    *pinned = 0;
-    QSAE_HIP(hipMemcpyAsync(pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    QSAE_HIP(hipEventRecord(copied, s));
-    QSAE_HIP(hipEventSynchronize(copied));
-    const int nflag = *pinned;
-    g_last_flagged = nflag;
+    // flagged rows: exact dense kernel on the gathered rows (the count comes back through this thread's pinned word)
+    ThreadDeviceCtx* ctx = nullptr;
+    rc = thread_device_ctx(&ctx);
+    if (rc != QSAE_OK) return rc;
+    *ctx->pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(ctx->pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipEventRecord(ctx->ev_copied, s));
+    QSAE_HIP(hipEventSynchronize(ctx->ev_copied));
+    const int nflag = *ctx->pinned;
     if (flagged_rows) *flagged_rows = nflag;
     float* fx = reinterpret_cast<float*>(ws + L.fx);
     uint32_t* fbits = reinterpret_cast<uint32_t*>(ws + L.fbits);
@@ -1409,35 +1481,9 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
 
 using namespace qsae;
 
-extern "C" int qsae_debug_sweep_timing(int enable) {
-    g_time_sweep = enable != 0;
-    return QSAE_OK;
-}
-
-// Sum of the sweep-kernel durations recorded since the last collect (caller has synchronised).
-extern "C" int qsae_debug_sweep_timing_collect(double* total_ms, int* launches) {
-    double tot = 0.0;
-    int n = 0;
-    for (auto& ev : g_sweep_events) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; ++n; }
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
-    g_sweep_events.clear();
-    if (total_ms) *total_ms = tot;
-    if (launches) *launches = n;
-    return QSAE_OK;
-}
-
+#ifdef QSAE_DEBUG_BUILD
+// ---- debug library only (libqsae_hip_debug.so): process-wide tuning / ablation switches ------------------------
 // fraction of the encoder FLOPs the sweep launch covers (the pilot block takes the rest)
-extern "C" double qsae_debug_sweep_flop_fraction(int H) {
-    // with the in-kernel pilot the sweep launch computes every hidden unit (the pilot block twice; only the
-    // algorithmic 2 B D H are counted)
-    if (g_inkernel_pilot && g_pref_tile == 2 && H % kXsHT == 0 && pilot_width(H) % kXsHT == 0) return 1.0;
-    return static_cast<double>(H - pilot_width(H)) / static_cast<double>(H);
-}
-
 extern "C" int qsae_debug_set_xstat_stamps(void* buf) {
     g_xstat_stamps = static_cast<unsigned long long*>(buf);
     return QSAE_OK;
@@ -1460,11 +1506,6 @@ extern "C" int qsae_debug_set_pilot(int div, int rank) {
 }
 
 // in-kernel pilot of the stationary sweep: enable (0 = separate pilot GEMM + selection), rank among 32 group maxima
-extern "C" int qsae_debug_set_spec_rows(int rows) {
-    kSpecRows = rows;
-    return QSAE_OK;
-}
-
 extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
     g_fuse_xprep = enable >= 2 ? 1 : 0;                      // 2 = in-kernel pilot + activation preparation fused into the sweep prologue
     enable = enable ? 1 : 0;
@@ -1472,8 +1513,6 @@ extern "C" int qsae_debug_set_inkernel_pilot(int enable, int rank) {
     g_inkernel_rank = rank;                                  // 0 = derive from k
     return QSAE_OK;
 }
-
-extern "C" int qsae_debug_last_flagged() { return g_last_flagged; }
 
 extern "C" int qsae_debug_set_fill_co(int v) {
     g_fill_co = v;
@@ -1503,6 +1542,27 @@ extern "C" int qsae_debug_set_sweep_kernel(int which) {
 extern "C" int qsae_debug_set_topk_path(int path) {
     g_force_path = path;
     return QSAE_OK;
+}
+
+// test hook: byte offsets of the approximate pilot block [B][P] fp32 and of margin[B] (= 2 eps_b) in the workspace
+extern "C" int qsae_debug_prefilter_offsets(int B, int D, int H, int k, size_t* pilot_off, size_t* margin_off,
+                                            int* pilot_cols) {
+    const FusedLayout L = fused_layout(B, D, H, k);
+    const PrefLayout PL = pref_layout(B, D, L.total);
+    if (pilot_off) *pilot_off = L.pilot;
+    if (margin_off) *margin_off = PL.margin;
+    if (pilot_cols) *pilot_cols = pilot_width(H);
+    return QSAE_OK;
+}
+#endif  // QSAE_DEBUG_BUILD
+
+// Fraction of the encoder's 2 B D H FLOPs that the profiled sweep launch (qsae_profile_sweep_events) covers: with the
+// in-kernel pilot the launch computes every hidden unit (the pilot sample twice; only the algorithmic work is
+// counted), otherwise the pilot block is a separate launch.
+extern "C" double qsae_profile_sweep_flop_fraction(int H) {
+    if (H <= 0) return 0.0;
+    if (g_inkernel_pilot && g_pref_tile == 2 && H % kXsHT == 0 && pilot_width(H) % kXsHT == 0) return 1.0;
+    return static_cast<double>(H - pilot_width(H)) / static_cast<double>(H);
 }
 
 extern "C" size_t qsae_encode_topk_workspace_bytes(int B, int D, int H, int k) {
@@ -1577,37 +1637,106 @@ extern "C" int qsae_prefilter_pack_w(const float* W, const float* bias, int H, i
     return QSAE_OK;
 }
 
-// test hook: byte offsets of the approximate pilot block [B][P] fp32 and of margin[B] (= 2 eps_b) in the workspace
-extern "C" int qsae_debug_prefilter_offsets(int B, int D, int H, int k, size_t* pilot_off, size_t* margin_off,
-                                            int* pilot_cols) {
-    const FusedLayout L = fused_layout(B, D, H, k);
-    const PrefLayout PL = pref_layout(B, D, L.total);
-    if (pilot_off) *pilot_off = L.pilot;
-    if (margin_off) *margin_off = PL.margin;
-    if (pilot_cols) *pilot_cols = pilot_width(H);
-    return QSAE_OK;
-}
-
 extern "C" size_t qsae_encode_topk_prefilter_workspace_bytes(int B, int D, int H, int k) {
     if (B <= 0 || H <= 0 || D <= 0 || k <= 0 || !prefilter_shape_ok(B, D, H, k)) return 0;
     return pref_layout(B, D, fused_layout(B, D, H, k).total).total_extra;
 }
 
+// Argument checks shared by the prefilter entry points; on success `call` (and `dec` when a dictionary is given) are filled.
+static int prefilter_call(const char* who, const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                          int B, int D, int H, int k, const uint8_t* packed, int n_bits, float step, const float* dec_bias,
+                          int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon, void* workspace,
+                          size_t workspace_bytes, qsae_stream_t stream, PrefCall& call, RowDecode& dec) {
+    if (!(x && W && Wq && meta && idx && val && workspace)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: null pointer", who);
+    if (!(k >= 1 && k <= H)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: 1 <= k <= H required", who);
+    if (!prefilter_shape_ok(B, D, H, k))
+        return fail(QSAE_ERR_UNSUPPORTED, "%s: unsupported: shape outside the prefilter's range (use qsae_encode_topk_latent)", who);
+    if (workspace_bytes < qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
+        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", who);
+    if (!(aligned16(workspace) && aligned16(x) && aligned16(W) && aligned16(Wq)))
+        return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: 16-byte alignment", who);
+    if (dense && !(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense)))
+        return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: dense latent alignment / ld", who);
+    call = PrefCall{x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, k, idx, val, static_cast<char*>(workspace),
+                    stream, dense, dense_ld, nullptr};
+    if (packed) {
+        if (!recon) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: packed given without recon", who);
+        if (!(n_bits >= 1 && n_bits <= 8)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: 1 <= n_bits <= 8 required", who);
+        if ((reinterpret_cast<uintptr_t>(packed) & 3u) != 0)
+            return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: packed must be 4-byte aligned", who);
+        dec = RowDecode{reinterpret_cast<const uint32_t*>(packed), qsae_binary_row_bytes(D, n_bits) / 4, n_bits,
+                        field_width(n_bits), D, step, dec_bias, recon};
+        call.dec = &dec;
+    }
+    return QSAE_OK;
+}
+
 extern "C" int qsae_encode_topk_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
                                           const float* meta, int B, int D, int H, int k, int32_t* idx, float* val,
                                           float* dense, int64_t dense_ld, void* workspace, size_t workspace_bytes,
-                                          qsae_stream_t stream) {
+                                          int spec_rows, int* flagged_rows, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (flagged_rows) *flagged_rows = 0;
+    if (B == 0) return QSAE_OK;
+    PrefCall call;
+    RowDecode dec;
+    const int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, nullptr, 0, 0.f, nullptr, idx, val, dense,
+                                  dense_ld, nullptr, workspace, workspace_bytes, stream, call, dec);
+    if (rc != QSAE_OK) return rc;
+    return run_prefilter(call, spec_rows, flagged_rows);
+}
+
+extern "C" int qsae_binary_forward_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                                             const float* meta, int B, int D, int H, int k, const uint8_t* packed,
+                                             int n_bits, float step, const float* dec_bias, int32_t* idx, float* val,
+                                             float* dense, int64_t dense_ld, float* recon, void* workspace,
+                                             size_t workspace_bytes, int spec_rows, int* flagged_rows,
+                                             qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (flagged_rows) *flagged_rows = 0;
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(packed && recon, "null pointer");
+    PrefCall call;
+    RowDecode dec;
+    const int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, packed, n_bits, step, dec_bias, idx, val, dense,
+                                  dense_ld, recon, workspace, workspace_bytes, stream, call, dec);
+    if (rc != QSAE_OK) return rc;
+    return run_prefilter(call, spec_rows, flagged_rows);
+}
+
+extern "C" int qsae_prefilter_submit(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                     int B, int D, int H, int k, const uint8_t* packed, int n_bits, float step,
+                                     const float* dec_bias, int32_t* idx, float* val, float* dense, int64_t dense_ld,
+                                     float* recon, void* workspace, size_t workspace_bytes, int* flagged_host,
+                                     qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    QSAE_CHECK_ARG(flagged_host != nullptr, "flagged_host must point to a host int");
+    if (B == 0) { *flagged_host = 0; return QSAE_OK; }
+    PrefCall call;
+    RowDecode dec;
+    int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, packed, n_bits, step, dec_bias, idx, val, dense,
+                            dense_ld, recon, workspace, workspace_bytes, stream, call, dec);
+    if (rc != QSAE_OK) return rc;
+    rc = prefilter_submit(call);
+    if (rc != QSAE_OK) return rc;
+    const PrefPlan pl = pref_plan(call);
+    QSAE_HIP(hipMemcpyAsync(flagged_host, call.ws + pl.L.flags, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+    return QSAE_OK;
+}
+
+extern "C" int qsae_prefilter_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                     int B, int D, int H, int k, const uint8_t* packed, int n_bits, float step,
+                                     const float* dec_bias, int32_t* idx, float* val, float* dense, int64_t dense_ld,
+                                     float* recon, void* workspace, size_t workspace_bytes, int flagged,
+                                     qsae_stream_t stream) {
     QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
     if (B == 0) return QSAE_OK;
-    QSAE_CHECK_ARG(x && W && Wq && meta && idx && val && workspace, "null pointer");
-    QSAE_CHECK_ARG(k >= 1 && k <= H, "1 <= k <= H required");
-    QSAE_CHECK_SUPPORTED(prefilter_shape_ok(B, D, H, k), "shape outside the prefilter's range (use qsae_encode_topk)");
-    if (workspace_bytes < qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
-        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", __func__);
-    QSAE_CHECK_ARG(aligned16(workspace) && aligned16(x) && aligned16(W) && aligned16(Wq), "16-byte alignment");
-    if (dense) QSAE_CHECK_ARG(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense), "dense latent alignment / ld");
-    return run_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, k, idx, val,
-                         static_cast<char*>(workspace), stream, dense, dense_ld);
+    PrefCall call;
+    RowDecode dec;
+    const int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, packed, n_bits, step, dec_bias, idx, val, dense,
+                                  dense_ld, recon, workspace, workspace_bytes, stream, call, dec);
+    if (rc != QSAE_OK) return rc;
+    return prefilter_finish(call, /*first=*/0, flagged);
 }
 
 extern "C" size_t qsae_encode_bits_prefilter_workspace_bytes(int B, int D, int H) {
@@ -1630,25 +1759,4 @@ extern "C" int qsae_encode_bits_prefilter(const float* x, const float* W, const 
     QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
     return run_bits_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld,
                               static_cast<char*>(workspace), stream, flagged_rows);
-}
-
-extern "C" int qsae_binary_forward_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
-                                             const float* meta, int B, int D, int H, int k, const uint8_t* packed,
-                                             int n_bits, float step, const float* dec_bias, int32_t* idx, float* val,
-                                             float* dense, int64_t dense_ld, float* recon, void* workspace,
-                                             size_t workspace_bytes, qsae_stream_t stream) {
-    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0 && k >= 1 && k <= H, "B >= 0, D > 0, H > 0, 1 <= k <= H required");
-    if (B == 0) return QSAE_OK;
-    QSAE_CHECK_ARG(x && W && Wq && meta && idx && val && packed && recon, "null pointer");
-    QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= 8, "1 <= n_bits <= 8 required");
-    QSAE_CHECK_SUPPORTED(prefilter_shape_ok(B, D, H, k), "shape outside the prefilter's range (use qsae_encode_topk_latent + qsae_decode_binary_sparse)");
-    if (!workspace || workspace_bytes < qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
-        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", __func__);
-    QSAE_CHECK_ARG(aligned16(workspace) && aligned16(x) && aligned16(W) && aligned16(Wq), "16-byte alignment");
-    QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 3u) == 0, "packed must be 4-byte aligned");
-    if (dense) QSAE_CHECK_ARG(dense_ld >= H && dense_ld % 4 == 0 && aligned16(dense), "dense latent alignment / ld");
-    const RowDecode d{reinterpret_cast<const uint32_t*>(packed), qsae_binary_row_bytes(D, n_bits) / 4, n_bits,
-                      field_width(n_bits), D, step, dec_bias, recon};
-    return run_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, k, idx, val,
-                         static_cast<char*>(workspace), stream, dense, dense_ld, &d);
 }

@@ -489,8 +489,13 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
 
 // Sweep length heuristic for kernels without row ownership: long enough to amortise the pipeline
 // fill, short enough to leave >= ~2048 workgroups for load balance.  g_sweep_override > 0 forces it.
+#ifdef QSAE_DEBUG_BUILD
 extern int g_sweep_override;
 extern int g_stagger;
+#else
+constexpr int g_sweep_override = 0;
+constexpr int g_stagger = 0;
+#endif
 template <int BM, int BN>
 inline int pick_sweep(int M, int N, int /*K*/) {
     if (g_sweep_override > 0) return g_sweep_override;
@@ -512,12 +517,7 @@ inline int launch_gemm(const typename LA::Args& la, const typename LB::Args& lb,
                        const typename Epi::Args& ea, int M, int N, int K, int sweep, hipStream_t stream) {
     auto kern = gemm_nt_f32_kernel<LA, LB, Epi, BM, BN, BK, ABLATE>;
     constexpr size_t lds = gemm_lds_bytes<BM, BN, BK>(Epi::kLdsFloats);
-    static bool configured = false;   // per instantiation
-    if (!configured) {
-        QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        configured = true;
-    }
+    QSAE_SET_MAX_LDS_ONCE(kern, lds);     // per instantiation and device
     SweepMap map;
     map.tiles_m = (M + BM - 1) / BM;
     map.tiles_n = (N + BN - 1) / BN;

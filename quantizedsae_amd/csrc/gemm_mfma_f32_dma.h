@@ -186,12 +186,7 @@ inline int launch_gemm_dma(const float* Rp, int M, const float* Cp, int N, int K
     auto kern = gemm_nt_f32_dma_kernel<Epi, BM, BN, HALF, STAGES>;
     constexpr size_t lds = (static_cast<size_t>(STAGES) * (BM + BN) * kDmaBK + Epi::kLdsFloats) * sizeof(float);
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static bool configured = false;
-    if (!configured) {
-        QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        configured = true;
-    }
+    QSAE_SET_MAX_LDS_ONCE(kern, lds);     // per instantiation and device
     if (K % kDmaBK != 0) return fail(QSAE_ERR_UNSUPPORTED, "%s: K must be a multiple of 32 words", __func__);
     SweepMap map;
     map.tiles_m = (M + BM - 1) / BM;

@@ -1,4 +1,6 @@
 // misc.hip -- library plumbing, dense-latent materialisation and the recon-MSE reduction.
+#include <map>
+
 #include "common.h"
 
 namespace qsae {
@@ -6,6 +8,32 @@ namespace qsae {
 char* last_error_buf() {
     static thread_local char buf[512] = {0};
     return buf;
+}
+
+// Helper objects of this host thread, one set per device it has used (common.h).  They live as long as the thread;
+// the handful of streams / events / pinned words is not reclaimed at thread exit (the runtime may already be gone).
+int thread_device_ctx(ThreadDeviceCtx** out) {
+    static thread_local std::map<int, ThreadDeviceCtx> table;
+    int dev = -1;
+    QSAE_HIP(hipGetDevice(&dev));
+    ThreadDeviceCtx& c = table[dev];
+    if (!c.side) {
+        QSAE_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        QSAE_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+        QSAE_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+        QSAE_HIP(hipEventCreateWithFlags(&c.ev_copied, hipEventDisableTiming));
+        QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(int), hipHostMallocDefault));
+    }
+    *out = &c;
+    return QSAE_OK;
+}
+
+static thread_local SweepProfile t_sweep_profile;
+
+SweepProfile take_sweep_profile() {
+    const SweepProfile p = t_sweep_profile;
+    t_sweep_profile = SweepProfile{};
+    return p;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -168,6 +196,12 @@ extern "C" int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, f
 }
 
 extern "C" int qsae_abi_version(void) { return QSAE_ABI_VERSION; }
+
+extern "C" int qsae_profile_sweep_events(void* ev_begin, void* ev_end) {
+    t_sweep_profile.begin = static_cast<hipEvent_t>(ev_begin);
+    t_sweep_profile.end = static_cast<hipEvent_t>(ev_end);
+    return QSAE_OK;
+}
 
 extern "C" const char* qsae_last_error(void) { return last_error_buf(); }
 

@@ -602,18 +602,16 @@ inline int launch_xstat_one(const XsArgs& a, hipStream_t stream) {
     constexpr size_t lds = static_cast<size_t>(kXsStages) * kXsHT * 16 * KB * 2 +
                            3 * kXsHT * 4 + static_cast<size_t>(kXsWaves) * kXsRingSlots * 256;
     auto kern = sweep_xstat_f16_kernel<KB, ABL>;
-    static bool configured = false;
-    if (!configured) {
-        QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds)));
-        configured = true;
-    }
+    QSAE_SET_MAX_LDS_ONCE(kern, lds);     // per instantiation and device
     hipLaunchKernelGGL(kern, dim3((a.B + kXsRows - 1) / kXsRows, a.parts), dim3(64 * kXsWaves), lds, stream, a);
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }
 
+// ablate: 0 = the complete kernel; 9 = the build without any zero-fill code (the product path when the zeros come from
+// the co-resident fill kernel); 1-8 = timing ablations whose results are wrong, instantiated in the debug library only.
 inline int launch_xstat(int D, const XsArgs& a, hipStream_t stream, int ablate = 0) {
+#ifdef QSAE_DEBUG_BUILD
     if (D == 512 && ablate == 1) return launch_xstat_one<32, 1>(a, stream);
     if (D == 512 && ablate == 2) return launch_xstat_one<32, 2>(a, stream);
     if (D == 512 && ablate == 3) return launch_xstat_one<32, 3>(a, stream);
@@ -622,6 +620,7 @@ inline int launch_xstat(int D, const XsArgs& a, hipStream_t stream, int ablate =
     if (D == 512 && ablate == 6) return launch_xstat_one<32, 6>(a, stream);
     if (D == 512 && ablate == 7) return launch_xstat_one<32, 7>(a, stream);
     if (D == 512 && ablate == 8) return launch_xstat_one<32, 8>(a, stream);
+#endif
     if (D == 512 && ablate == 9) return launch_xstat_one<32, 9>(a, stream);
     switch (D) {
         case 512: return launch_xstat_one<32>(a, stream);

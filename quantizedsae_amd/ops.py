@@ -5,6 +5,7 @@ tensors and raises otherwise -- there is no CPU path in this package.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -17,17 +18,67 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_tensor_device(fn):
+    """Run `fn` with the device of its first tensor argument current: the C ABI (like any HIP library) launches on the
+    current device, and a model moved to cuda:1 must not launch on cuda:0 because that is what the thread last used."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+class _HipEventPair:
+    """Two timing events created through the HIP runtime itself (no dependence on how torch wraps its events): the
+    library records them around its candidate-sweep launch on the launch stream (qsae_profile_sweep_events)."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            cls._hip = C.CDLL("libamdhip64.so")
+            cls._hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+            cls._hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            cls._hip.hipEventDestroy.argtypes = [C.c_void_p]
+        return cls._hip
+
+    def __init__(self):
+        self.a, self.b = C.c_void_p(), C.c_void_p()
+        for e in (self.a, self.b):
+            if self.hip().hipEventCreate(C.byref(e)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+
+    def elapsed_ms(self):
+        ms = C.c_float(0.0)
+        return ms.value if self.hip().hipEventElapsedTime(C.byref(ms), self.a, self.b) == 0 else None
+
+    def destroy(self):
+        for e in (self.a, self.b):
+            self.hip().hipEventDestroy(e)
+
+
 class _KernelTimer:
-    """Optional HIP-event bracket around selected launches (used by bench.py to time the dominant
-    kernel live inside the timed region).  Events are recorded on the stream the kernel is launched
-    on (torch's current stream) and read only after the region has been synchronised."""
+    """Optional HIP-event brackets (used by bench.py to time the dominant kernel live inside the timed region).
+    `encode_dense` launches are bracketed here; the candidate sweep is launched inside the library, which records a
+    pair handed to it per call (sweep_pairs).  All events sit on the stream the kernel is launched on and are read only
+    after the region has been synchronised."""
 
     def __init__(self):
         self.enabled = False
+        self.sweep = False          # hand an event pair to every fused / prefilter call
         self._events = {}
+        self._sweep_pairs = []
 
     def reset(self):
         self._events = {}
+        for p in self._sweep_pairs:
+            p.destroy()
+        self._sweep_pairs = []
 
     def bracket(self, name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,26 +91,31 @@ class _KernelTimer:
             return None
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
+    def arm_sweep(self):
+        """Called right before a library call that contains a candidate sweep."""
+        if self.sweep:
+            p = _HipEventPair()
+            self._sweep_pairs.append(p)
+            check(_lib.load().qsae_profile_sweep_events(p.a, p.b))
+
+    def sweep_mean_ms(self):
+        """-> (mean ms per sweep launch or None, launches); the region must have been synchronised."""
+        ms = [m for m in (p.elapsed_ms() for p in self._sweep_pairs) if m is not None]
+        return (sum(ms) / len(ms) if ms else None), len(ms)
+
 
 kernel_timer = _KernelTimer()
 
 
 def sweep_timing(enable: bool) -> None:
-    """Bracket the fused path's sweep kernel (launched inside qsae_encode_topk) with HIP events."""
-    lib = _lib.load()
-    lib.qsae_debug_sweep_timing.argtypes = [C.c_int]
-    lib.qsae_debug_sweep_timing(1 if enable else 0)
+    """Time the candidate-sweep launch of every following fused / prefilter call (HIP events on the launch stream)."""
+    kernel_timer.sweep = bool(enable)
 
 
 def sweep_timing_collect(H: int):
     """-> (mean ms per sweep launch or None, launches, fraction of the encoder FLOPs per launch)."""
-    lib = _lib.load()
-    lib.qsae_debug_sweep_timing_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
-    lib.qsae_debug_sweep_flop_fraction.argtypes = [C.c_int]
-    lib.qsae_debug_sweep_flop_fraction.restype = C.c_double
-    tot, n = C.c_double(0.0), C.c_int(0)
-    lib.qsae_debug_sweep_timing_collect(C.byref(tot), C.byref(n))
-    return (tot.value / n.value if n.value else None), n.value, float(lib.qsae_debug_sweep_flop_fraction(H))
+    ms, n = kernel_timer.sweep_mean_ms()
+    return ms, n, float(_lib.load().qsae_profile_sweep_flop_fraction(H))
 
 
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
@@ -85,6 +141,7 @@ def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
 
 
 # ---- encoder ------------------------------------------------------------------------------
+@_on_tensor_device
 def kperm_rows(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K-interleaved copy of a [rows, K] fp32 matrix (K % 8 == 0); see qsae_kperm_rows."""
     src = _f32c(src, "src")
@@ -95,6 +152,7 @@ def kperm_rows(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
+@_on_tensor_device
 def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
                  out: Optional[torch.Tensor] = None, kperm: bool = False) -> torch.Tensor:
     """kperm=True: x and W are already K-interleaved (kperm_rows)."""
@@ -116,6 +174,7 @@ def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+@_on_tensor_device
 def encode_bits(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """uint32-packed z bits [B, ceil(H/32)] (returned as int32 tensor)."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
@@ -132,6 +191,7 @@ def encode_bits_prefilter_supported(B: int, D: int, H: int) -> bool:
     return B > 0 and int(_lib.load().qsae_encode_bits_prefilter_workspace_bytes(B, D, H)) > 0
 
 
+@_on_tensor_device
 def encode_bits_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
                           meta: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """z bits identical to encode_bits, from the fp16 candidate sweep + exact re-evaluation of the latents near the
@@ -150,11 +210,13 @@ def encode_bits_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     words = (H + 31) // 32
     z = torch.empty((B, words), dtype=torch.int32, device=x.device)
     flagged = C.c_int(0)
+    kernel_timer.arm_sweep()
     check(lib.qsae_encode_bits_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, _p(z), words, _p(ws),
                                          ws.numel(), C.byref(flagged), _stream()))
     return z, int(flagged.value)
 
 
+@_on_tensor_device
 def topk_rows(latent: torch.Tensor, k: int, zero_rest: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """In-place on `latent` when zero_rest.  Returns (idx int32 [B,k], val f32 [B,k])."""
     _dev(latent, "latent", torch.float32)
@@ -171,14 +233,27 @@ def topk_rows(latent: torch.Tensor, k: int, zero_rest: bool) -> Tuple[torch.Tens
 _workspaces = {}
 
 
-def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
+def _workspace(device: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
+    """Scratch for one call in flight: one buffer per (device, stream, slot).  Two streams never share one (their
+    kernels would write the same candidate lists), and a buffer that has to grow is simply replaced: the old block goes
+    back to the caching allocator, which reuses memory in the order of the stream it was allocated on -- the same
+    stream every user of this buffer ran on.  `slot` separates batches that are in flight together on one stream
+    (submit / finish)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream, slot)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 
+def release_workspaces() -> None:
+    """Drop every cached scratch buffer (they are re-created on demand)."""
+    _workspaces.clear()
+
+
+@_on_tensor_device
 def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], k: int, kperm: bool = False):
     """kperm=True: x and W are already K-interleaved (kperm_rows)."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
@@ -191,10 +266,12 @@ def encode_topk(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], 
     idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
     fn = lib.qsae_encode_topk_kperm if kperm else lib.qsae_encode_topk
+    kernel_timer.arm_sweep()
     check(fn(_p(x), _p(W), _p(b), B, D, H, k, _p(idx), _p(val), _p(ws), ws.numel(), _stream()))
     return idx, val
 
 
+@_on_tensor_device
 def encode_topk_latent(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], k: int, kperm: bool = False):
     """-> (idx, val, dense latent [B,H]); the dense tensor is zero-filled inside the encoder sweep."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
@@ -207,11 +284,13 @@ def encode_topk_latent(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Te
     idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
     dense = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    kernel_timer.arm_sweep()
     check(lib.qsae_encode_topk_latent(_p(x), _p(W), _p(b), B, D, H, k, _p(idx), _p(val), _p(dense), H,
                                       1 if kperm else 0, _p(ws), ws.numel(), _stream()))
     return idx, val, dense
 
 
+@_on_tensor_device
 def prefilter_pack_w(W: torch.Tensor, bias: Optional[torch.Tensor]):
     """-> (Wq fp16 [H, D], meta fp32 [4]) for encode_topk_prefilter (once per checkpoint)."""
     W = _f32c(W, "W")
@@ -227,10 +306,14 @@ def prefilter_supported(B: int, D: int, H: int, k: int) -> bool:
     return int(_lib.load().qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k)) > 0
 
 
+@_on_tensor_device
 def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
-                          meta: torch.Tensor, k: int, want_dense: bool = True, dense_out: Optional[torch.Tensor] = None):
+                          meta: torch.Tensor, k: int, want_dense: bool = True, dense_out: Optional[torch.Tensor] = None,
+                          spec_rows: int = 0, info: Optional[dict] = None):
     """fp16-prefiltered encoder + exact top-k (+ dense latent): results identical to encode_topk_latent.
-    ``dense_out``: optional [B, >=H] fp32 buffer (row stride a multiple of 4) that receives the dense latent."""
+    ``dense_out``: optional [B, >=H] fp32 buffer (row stride a multiple of 4) that receives the dense latent.
+    ``spec_rows``: flagged rows the device recomputes while the host waits for their count (see qsae.h).
+    ``info``: a dict that receives ``flagged_rows`` (rows that went through the exact fallback kernels)."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
     B, D = x.shape
     H = W.shape[0]
@@ -250,37 +333,91 @@ def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     else:
         dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
         ld = H
+    flagged = C.c_int(0)
+    kernel_timer.arm_sweep()
     check(lib.qsae_encode_topk_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(idx), _p(val),
-                                         _p(dense), ld, _p(ws), ws.numel(), _stream()))
+                                         _p(dense), ld, _p(ws), ws.numel(), int(spec_rows), C.byref(flagged), _stream()))
+    if info is not None:
+        info["flagged_rows"] = int(flagged.value)
     return idx, val, (dense[:, :H] if dense_out is not None else dense)
 
 
-def binary_forward_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
-                             meta: torch.Tensor, k: int, packed: torch.Tensor, n_bits: int, step: float,
-                             dec_bias: Optional[torch.Tensor], want_dense: bool = True):
-    """encode_topk_prefilter + decode_binary_sparse in one call (rows are decoded by the refinement kernel as it
-    ranks them): (idx, val, dense latent or None, reconstruction), bit-identical to the two separate calls."""
+def _binary_prefilter_args(x, W, bias, Wq, meta, k, packed, n_bits, step, dec_bias, want_dense, slot):
     x, W = _f32c(x, "x"), _f32c(W, "W")
     _dev(packed, "packed", torch.uint8)
     B, D = x.shape
     H = W.shape[0]
     b = _f32c(bias, "bias") if bias is not None else None
     db = _f32c(dec_bias, "dec_bias") if dec_bias is not None else None
-    lib = _lib.load()
-    need = int(lib.qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
+    need = int(_lib.load().qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
     if need == 0:
         raise ValueError("shape not supported by the fp16 prefilter")
-    ws = _workspace(x.device, need)
+    ws = _workspace(x.device, need, slot)
     idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
     dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
     recon = torch.empty((B, D), dtype=torch.float32, device=x.device)
-    check(lib.qsae_binary_forward_prefilter(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(packed), n_bits,
-                                            float(step), _p(db), _p(idx), _p(val), _p(dense), H, _p(recon), _p(ws),
-                                            ws.numel(), _stream()))
-    return idx, val, dense, recon
+    cargs = (_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(packed), n_bits, float(step), _p(db), _p(idx), _p(val),
+             _p(dense), H, _p(recon), _p(ws), ws.numel())
+    keep = (x, W, b, Wq, meta, packed, db, ws)          # referenced by the pointers above
+    return cargs, keep, (idx, val, dense, recon)
 
 
+@_on_tensor_device
+def binary_forward_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                             meta: torch.Tensor, k: int, packed: torch.Tensor, n_bits: int, step: float,
+                             dec_bias: Optional[torch.Tensor], want_dense: bool = True, spec_rows: int = 0,
+                             info: Optional[dict] = None):
+    """encode_topk_prefilter + decode_binary_sparse in one call (rows are decoded by the refinement kernel as it
+    ranks them): (idx, val, dense latent or None, reconstruction), bit-identical to the two separate calls."""
+    cargs, keep, outs = _binary_prefilter_args(x, W, bias, Wq, meta, k, packed, n_bits, step, dec_bias, want_dense, 0)
+    flagged = C.c_int(0)
+    kernel_timer.arm_sweep()
+    check(_lib.load().qsae_binary_forward_prefilter(*cargs, int(spec_rows), C.byref(flagged), _stream()))
+    if info is not None:
+        info["flagged_rows"] = int(flagged.value)
+    return outs
+
+
+class PendingForward:
+    """A batch whose main kernels are queued (binary_forward_prefilter_submit).  ``finish()`` waits for the 4-byte
+    count of rows that need the exact fallback -- by then the GPU is usually busy with the NEXT batch's kernels --
+    enqueues that fallback and returns (idx, val, dense latent or None, reconstruction).  The outputs must not be read
+    before ``finish()`` has returned.  Not safe to share between threads."""
+
+    def __init__(self, cargs, keep, outs, word, event, device):
+        self._cargs, self._keep, self._outs, self._word, self._event, self._device = cargs, keep, outs, word, event, device
+        self.flagged_rows = None
+
+    def finish(self):
+        if self._cargs is None:
+            return self._outs
+        self._event.synchronize()                      # the count has landed in the pinned word
+        self.flagged_rows = int(self._word.item())
+        with torch.cuda.device(self._device):
+            check(_lib.load().qsae_prefilter_finish(*self._cargs, self.flagged_rows, _stream()))
+        self._cargs = self._keep = None
+        return self._outs
+
+
+@_on_tensor_device
+def binary_forward_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                                    meta: torch.Tensor, k: int, packed: torch.Tensor, n_bits: int, step: float,
+                                    dec_bias: Optional[torch.Tensor], want_dense: bool = True,
+                                    slot: int = 0) -> PendingForward:
+    """The two-call form of binary_forward_prefilter (qsae_prefilter_submit / _finish): nothing in here waits for the
+    GPU, so the caller can submit batch i+1 before it finishes batch i.  Batches in flight together on one stream
+    need different ``slot`` numbers (each slot is a workspace of its own); finish them in submission order."""
+    cargs, keep, outs = _binary_prefilter_args(x, W, bias, Wq, meta, k, packed, n_bits, step, dec_bias, want_dense, slot)
+    word = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    kernel_timer.arm_sweep()
+    check(_lib.load().qsae_prefilter_submit(*cargs, C.c_void_p(word.data_ptr()), _stream()))
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingForward(cargs, keep, outs, word, ev, x.device)
+
+
+@_on_tensor_device
 def densify(idx: torch.Tensor, val: torch.Tensor, H: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(idx, "idx", torch.int32)
     _dev(val, "val", torch.float32)
@@ -300,18 +437,22 @@ def binary_row_bytes(D: int, n_bits: int) -> int:
     return r
 
 
-def pack_binary(logits: torch.Tensor, D: int, n_bits: int, want_polarize: bool = True):
-    """-> (packed uint8 [H, row_bytes], polarize_sum float64 0-d tensor or None)."""
+@_on_tensor_device
+def pack_binary(logits: torch.Tensor, D: int, n_bits: int, want_polarize: bool = True, want_soft_gap: bool = False):
+    """-> (packed uint8 [H, row_bytes], polarize_sum float64 0-d tensor or None[, soft_gap float32 0-d tensor]).
+    soft_gap = max |soft integer - hard integer| over the dictionary (see qsae_pack_binary)."""
     logits = _f32c(logits, "logits")
     H = logits.shape[0]
     if logits.shape[1] != D * n_bits:
         raise ValueError(f"logits is {tuple(logits.shape)}, expected [H, {D * n_bits}]")
     packed = torch.empty((H, binary_row_bytes(D, n_bits)), dtype=torch.uint8, device=logits.device)
     pol = torch.zeros((), dtype=torch.float64, device=logits.device) if want_polarize else None
-    check(_lib.load().qsae_pack_binary(_p(logits), H, D, n_bits, _p(packed), _p(pol), _stream()))
-    return packed, pol
+    gap = torch.zeros((), dtype=torch.float32, device=logits.device) if want_soft_gap else None
+    check(_lib.load().qsae_pack_binary(_p(logits), H, D, n_bits, _p(packed), _p(pol), _p(gap), _stream()))
+    return (packed, pol, gap) if want_soft_gap else (packed, pol)
 
 
+@_on_tensor_device
 def unpack_binary(packed: torch.Tensor, D: int, n_bits: int) -> torch.Tensor:
     _dev(packed, "packed", torch.uint8)
     H = packed.shape[0]
@@ -320,6 +461,7 @@ def unpack_binary(packed: torch.Tensor, D: int, n_bits: int) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def binary_soft_table(logits: torch.Tensor, D: int, n_bits: int) -> torch.Tensor:
     logits = _f32c(logits, "logits")
     H = logits.shape[0]
@@ -328,6 +470,7 @@ def binary_soft_table(logits: torch.Tensor, D: int, n_bits: int) -> torch.Tensor
     return out
 
 
+@_on_tensor_device
 def decode_binary_sparse(idx, val, packed, D: int, n_bits: int, step: float, bias=None) -> torch.Tensor:
     _dev(idx, "idx", torch.int32)
     _dev(val, "val", torch.float32)
@@ -341,6 +484,7 @@ def decode_binary_sparse(idx, val, packed, D: int, n_bits: int, step: float, bia
     return recon
 
 
+@_on_tensor_device
 def decode_table_sparse(idx, val, table: torch.Tensor, scale: float = 1.0, bias=None) -> torch.Tensor:
     _dev(idx, "idx", torch.int32)
     _dev(val, "val", torch.float32)
@@ -355,6 +499,7 @@ def decode_table_sparse(idx, val, table: torch.Tensor, scale: float = 1.0, bias=
 
 
 # ---- ternary ---------------------------------------------------------------------------------
+@_on_tensor_device
 def pack_ternary(w: torch.Tensor) -> torch.Tensor:
     """decoder.weight [D, H] -> 2-bit codes int32 [D, ceil(H/16)]."""
     w = _f32c(w, "w")
@@ -364,6 +509,7 @@ def pack_ternary(w: torch.Tensor) -> torch.Tensor:
     return codes
 
 
+@_on_tensor_device
 def decode_ternary_dense(h: torch.Tensor, codes: torch.Tensor, D: int) -> torch.Tensor:
     _dev(h, "h", torch.float32)
     B, H = h.shape
@@ -389,6 +535,7 @@ def _sizes_arg(sizes, n_bits):
     return arr, C.cast(arr, C.c_void_p)
 
 
+@_on_tensor_device
 def pack_matryoshka(w: torch.Tensor, wm: torch.Tensor, n_bits: int, abs_range: float, sizes=None):
     """-> (codes int32 [D, ceil(H/16)] of S/2, scale fp32 [H])."""
     w, wm = _f32c(w, "w"), _f32c(wm, "wm")
@@ -401,6 +548,7 @@ def pack_matryoshka(w: torch.Tensor, wm: torch.Tensor, n_bits: int, abs_range: f
     return codes, scale
 
 
+@_on_tensor_device
 def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, scale, bias, allow_bias: bool,
                       sizes=None):
     """-> (levels f32 [n_bits, B, D], l0_counts int64 [n_bits])."""
@@ -416,6 +564,7 @@ def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, s
     return levels, counts
 
 
+@_on_tensor_device
 def pack_matryoshka_rows(w: torch.Tensor, wm: torch.Tensor) -> torch.Tensor:
     """-> codes_rows int32 [H, ceil(D/16)]: the dictionary in hidden-major order for decode_matryoshka_sparse."""
     w, wm = _f32c(w, "w"), _f32c(wm, "wm")
@@ -429,6 +578,7 @@ def decode_matryoshka_sparse_supported(D: int) -> bool:
     return D in (64, 128, 256, 512, 1024)
 
 
+@_on_tensor_device
 def decode_matryoshka_sparse(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes_rows, scale, bias,
                              allow_bias: bool, sizes=None):
     """decode_matryoshka on the active units only (same outputs)."""
@@ -444,6 +594,7 @@ def decode_matryoshka_sparse(zbits: torch.Tensor, H: int, D: int, n_bits: int, c
     return levels, counts
 
 
+@_on_tensor_device
 def pack_bits_gt(dense: torch.Tensor, thr: float) -> torch.Tensor:
     """int32-packed bits [B, ceil(H/32)] of (dense > thr)."""
     _dev(dense, "dense", torch.float32)
@@ -458,6 +609,7 @@ def pack_bits_gt(dense: torch.Tensor, thr: float) -> torch.Tensor:
 
 
 # ---- metric ------------------------------------------------------------------------------------
+@_on_tensor_device
 def sq_err_sum(recon: torch.Tensor, x: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
     """acc (float64 0-d device tensor) += sum((recon - x)^2); returns acc (no host sync)."""
     recon, x = _f32c(recon, "recon"), _f32c(x, "x")
@@ -470,6 +622,7 @@ def sq_err_sum(recon: torch.Tensor, x: torch.Tensor, acc: Optional[torch.Tensor]
 
 
 # ---- consumers of the sparse latent (activation statistics) ---------------------------------------------
+@_on_tensor_device
 def activation_counts(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
                       counts: Optional[torch.Tensor] = None) -> torch.Tensor:
     """counts[h] += #rows whose entry h is active (val > 0; every listed entry when val is None).  int64 [H]."""
@@ -484,6 +637,7 @@ def activation_counts(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
     return counts
 
 
+@_on_tensor_device
 def activation_counts_bits(zbits: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
     """counts[32 w + j] += popcount over rows of bit j of word w.  zbits int32 [B, words]; int64 [32 * words]."""
     _dev(zbits, "zbits", torch.int32)
@@ -495,6 +649,7 @@ def activation_counts_bits(zbits: torch.Tensor, counts: Optional[torch.Tensor] =
     return counts
 
 
+@_on_tensor_device
 def coactivation_sparse(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
                         coact: Optional[torch.Tensor] = None) -> torch.Tensor:
     """coact[a, c] += #rows in which units a and c are both active (mask^T @ mask).  int32 [H, H]."""
@@ -509,6 +664,7 @@ def coactivation_sparse(idx: torch.Tensor, val: Optional[torch.Tensor], H: int,
     return coact
 
 
+@_on_tensor_device
 def quantize_bits(x: torch.Tensor, n_bits: int, scale_factor: float, signed: bool = True) -> torch.Tensor:
     """n-bit code of every activation as LSB-first 0/1 floats, [B, D * n_bits] (data/dataset.py:76-102)."""
     x = _f32c(x, "x")

@@ -17,6 +17,7 @@ class BaselineSparseAutoencoder(nn.Module):
         self.latent_path = "auto"      # "auto" | "prefilter" | "fused" | "inplace" (see BinarySAE.latent_path)
         self._cache = PackedCache()
         self._pref_cache = PackedCache()
+        self.last_flagged_rows = 0     # rows of the previous prefilter batch that took the exact fallback (per model)
 
     def _table(self) -> torch.Tensor:
         # decoder.weight is [D, H]; the sparse decode gathers rows of its transpose [H, D]
@@ -35,8 +36,11 @@ class BaselineSparseAutoencoder(nn.Module):
                 pw = self._pref_cache.get((lin.weight, lin.bias), lambda: dict(zip(
                     ("Wq", "meta"), ops.prefilter_pack_w(lin.weight.detach(), lin.bias.detach()))))
                 xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                info = {}
                 idx, val, h = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
-                                                        self.topk)
+                                                        self.topk, spec_rows=32 if self.last_flagged_rows > 0 else 0,
+                                                        info=info)
+                self.last_flagged_rows = info["flagged_rows"]
             elif big and self.latent_path != "inplace":
                 xp, Wp, kperm = self.encoder.operands(x)
                 idx, val, h = ops.encode_topk_latent(xp, Wp, lin.bias, self.topk, kperm=kperm)
@@ -58,12 +62,23 @@ class BaselineSparseAutoencoder(nn.Module):
                 pw = self._pref_cache.get((lin.weight, lin.bias), lambda: dict(zip(
                     ("Wq", "meta"), ops.prefilter_pack_w(lin.weight.detach(), lin.bias.detach()))))
                 xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+                info = {}
                 idx, val, _ = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
-                                                        self.topk, want_dense=False)
+                                                        self.topk, want_dense=False,
+                                                        spec_rows=32 if self.last_flagged_rows > 0 else 0, info=info)
+                self.last_flagged_rows = info["flagged_rows"]
             else:
                 xp, Wp, kperm = self.encoder.operands(x)
                 idx, val = ops.encode_topk(xp, Wp, lin.bias, self.topk, kperm=kperm)
             return idx, val, ops.decode_table_sparse(idx, val, self._table(), 1.0, self.decoder.bias.detach())
+
+    def invalidate_packed(self) -> None:
+        """Forget the derived weight copies (transposed decoder table, fp16 / K-interleaved encoder copies): needed only
+        after an in-place edit through ``.data`` -- normalize_decoder_weights() below does it itself."""
+        self._cache.clear()
+        self._pref_cache.clear()
+        if hasattr(self.encoder, "_kperm_cache"):
+            self.encoder._kperm_cache.clear()
 
     def apply_topk_activation(self, h):
         """Dense in, dense out: keep the top-k entries of every row (sae/baseline.py:33-40)."""
@@ -77,3 +92,4 @@ class BaselineSparseAutoencoder(nn.Module):
         with torch.no_grad():
             w = self.decoder.weight.data
             self.decoder.weight.data = w / torch.clamp(torch.norm(w, dim=0, keepdim=True), min=1e-8)
+            self.invalidate_packed()

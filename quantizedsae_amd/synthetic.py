@@ -69,13 +69,19 @@ def xavier_uniform(seed: int, fan_out: int, fan_in: int, stream: int = 0) -> np.
 
 
 def binary_sae_params(seed: int, D: int, H: int, n_bits: int, logit_mag: float = 30.0,
-                      enc_bias_std: float = 0.0, dec_bias_std: float = 0.0) -> dict:
-    """BinarySAE state_dict (binary.py:73-89): xavier encoder, saturated +-logit_mag decoder bits."""
-    bits = fair_bits(seed, (H, D * n_bits), stream=2).astype(np.float32)
+                      enc_bias_std: float = 0.0, dec_bias_std: float = 0.0, logit_std: float = None) -> dict:
+    """BinarySAE state_dict (binary.py:73-89): xavier encoder, saturated +-logit_mag decoder bits -- or, with
+    logit_std, unpolarised bell-shaped logits of that standard deviation (logit_std = sqrt(2 / (D n_bits)) is the
+    reference's default kaiming init, binary.py:22)."""
+    if logit_std is not None:
+        dec_w = normal(seed, (H, D * n_bits), stream=2, std=logit_std)
+    else:
+        bits = fair_bits(seed, (H, D * n_bits), stream=2).astype(np.float32)
+        dec_w = ((bits * 2.0 - 1.0) * np.float32(logit_mag)).astype(np.float32)
     sd = {
         "encoder.0.weight": xavier_uniform(seed, H, D, stream=1),
         "encoder.0.bias": (normal(seed, (H,), stream=3, std=enc_bias_std) if enc_bias_std else np.zeros((H,), np.float32)),
-        "decoder.weight": ((bits * 2.0 - 1.0) * np.float32(logit_mag)).astype(np.float32),
+        "decoder.weight": dec_w,
         "decoder.bias": (normal(seed, (D,), stream=4, std=dec_bias_std) if dec_bias_std else np.zeros((D,), np.float32)),
     }
     return sd

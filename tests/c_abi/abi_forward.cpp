@@ -117,11 +117,19 @@ int main(int argc, char** argv) {
     const size_t ws_exact = qsae_encode_topk_workspace_bytes(B, D, H, k);
     HIP_OK(hipMalloc(&dws, prefilter ? ws_bytes : (ws_exact ? ws_exact : 256)));
 
-    QSAE_OK_OR_DIE(qsae_pack_binary(dlogits, H, D, n_bits, dpacked, nullptr, stream));        // once per checkpoint
+    float* dgap;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&dgap), sizeof(float)));
+    QSAE_OK_OR_DIE(qsae_pack_binary(dlogits, H, D, n_bits, dpacked, nullptr, dgap, stream));  // once per checkpoint
+    float gap = -1.f;
+    HIP_OK(hipMemcpyAsync(&gap, dgap, sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (!(gap >= 0.f && gap < 1e-6f)) { printf("FAIL soft/hard gap %g: the fixture's logits are saturated\n", gap); return 1; }
     if (prefilter) {
         QSAE_OK_OR_DIE(qsae_prefilter_pack_w(dW, dbias_enc, H, D, dWq, dmeta, stream));
+        int flagged = -1;
         QSAE_OK_OR_DIE(qsae_encode_topk_prefilter(dx, dW, dbias_enc, dWq, dmeta, B, D, H, k, didx, dval, ddense, H, dws,
-                                                  ws_bytes, stream));
+                                                  ws_bytes, /*spec_rows=*/0, &flagged, stream));
+        if (flagged < 0 || flagged > B) { printf("FAIL flagged-row count %d\n", flagged); return 1; }
     } else {
         QSAE_OK_OR_DIE(qsae_encode_topk_latent(dx, dW, dbias_enc, B, D, H, k, didx, dval, ddense, H, 0, dws, ws_exact, stream));
     }
@@ -138,12 +146,37 @@ int main(int argc, char** argv) {
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&dval2), static_cast<size_t>(B) * k * 4));
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&drecon2), static_cast<size_t>(B) * D * 4));
         QSAE_OK_OR_DIE(qsae_binary_forward_prefilter(dx, dW, dbias_enc, dWq, dmeta, B, D, H, k, dpacked, n_bits, step, dbias_dec,
-                                                     didx2, dval2, nullptr, 0, drecon2, dws, ws_bytes, stream));
+                                                     didx2, dval2, nullptr, 0, drecon2, dws, ws_bytes, /*spec_rows=*/32, nullptr,
+                                                     stream));
         HIP_OK(hipStreamSynchronize(stream));
         frecon.resize(static_cast<size_t>(B) * D);
         fidx.resize(static_cast<size_t>(B) * k);
         HIP_OK(hipMemcpy(frecon.data(), drecon2, frecon.size() * 4, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(fidx.data(), didx2, fidx.size() * 4, hipMemcpyDeviceToHost));
+        // ... and as submit / finish, the host waiting on its own event instead of inside the library
+        int* flagged_host;
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&flagged_host), sizeof(int), hipHostMallocDefault));
+        *flagged_host = -1;
+        hipEvent_t landed;
+        HIP_OK(hipEventCreateWithFlags(&landed, hipEventDisableTiming));
+        HIP_OK(hipMemsetAsync(drecon2, 0xFF, static_cast<size_t>(B) * D * 4, stream));
+        HIP_OK(hipMemsetAsync(didx2, 0xFF, static_cast<size_t>(B) * k * 4, stream));
+        QSAE_OK_OR_DIE(qsae_prefilter_submit(dx, dW, dbias_enc, dWq, dmeta, B, D, H, k, dpacked, n_bits, step, dbias_dec, didx2,
+                                             dval2, nullptr, 0, drecon2, dws, ws_bytes, flagged_host, stream));
+        HIP_OK(hipEventRecord(landed, stream));
+        HIP_OK(hipEventSynchronize(landed));
+        if (*flagged_host < 0 || *flagged_host > B) { printf("FAIL submit: flagged-row count %d\n", *flagged_host); return 1; }
+        QSAE_OK_OR_DIE(qsae_prefilter_finish(dx, dW, dbias_enc, dWq, dmeta, B, D, H, k, dpacked, n_bits, step, dbias_dec, didx2,
+                                             dval2, nullptr, 0, drecon2, dws, ws_bytes, *flagged_host, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<float> srecon(frecon.size());
+        std::vector<int32_t> sidx(fidx.size());
+        HIP_OK(hipMemcpy(srecon.data(), drecon2, srecon.size() * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(sidx.data(), didx2, sidx.size() * 4, hipMemcpyDeviceToHost));
+        if (memcmp(srecon.data(), frecon.data(), frecon.size() * 4) != 0 || memcmp(sidx.data(), fidx.data(), fidx.size() * 4) != 0) {
+            printf("FAIL submit / finish differs from the one-call forward\n");
+            return 1;
+        }
     }
 
     std::vector<int32_t> gidx(oidx.size());

@@ -36,7 +36,8 @@ class Fixture:
         v = m["variant"]
         if v == "binary":
             sd = S.binary_sae_params(m["seed"], m["D"], m["H"], m["n_bits"], logit_mag=m["logit_mag"],
-                                     enc_bias_std=m["enc_bias_std"], dec_bias_std=m["dec_bias_std"])
+                                     enc_bias_std=m["enc_bias_std"], dec_bias_std=m["dec_bias_std"],
+                                     logit_std=m.get("logit_std"))
         elif v == "baseline":
             sd = S.baseline_sae_params(m["seed"], m["D"], m["H"], bias_std=m["bias_std"])
         elif v == "ternary":
@@ -63,7 +64,8 @@ class Fixture:
                 assert np.array_equal(sd[k[3:]], a), f"{self.name}: PRNG drifted for {k}"
         if "dec_bits" in self.arrays:
             bits = np.unpackbits(self.arrays["dec_bits"], axis=1)[:, : m["D"] * m["n_bits"]]
-            assert np.array_equal(bits, (sd["decoder.weight"] > 0).astype(np.uint8))
+            # bit = sigmoid(w) > 0.5; on the saturated fixtures that is w > 0, on the unpolarised ones the packer's cutoff
+            assert np.array_equal(bits, (sd["decoder.weight"] >= np.float32(8.9406974e-08)).astype(np.uint8))
         return sd
 
 

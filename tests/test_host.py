@@ -29,7 +29,26 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared          # the ctypes table binds exactly the header
-    assert _lib.load().qsae_abi_version() == 1
+    assert _lib.load().qsae_abi_version() == 2
+
+
+def test_product_library_has_no_debug_surface():
+    """The shipped library exports exactly the C ABI of include/qsae.h: no qsae_debug_* switch, no process-wide
+    tunable.  Those live in libqsae_hip_debug.so (same sources, -DQSAE_DEBUG_BUILD), which tools/ and a few tests load
+    explicitly; it must offer the whole ABI as well."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+    from quantizedsae_amd import build
+    declared = set(ge.declared_symbols())
+    prod = [s_ for s_ in build.exported_symbols(_lib.LIB_PATH) if s_.startswith("qsae_")]
+    assert set(prod) == declared, sorted(set(prod) ^ declared)
+    assert not [s_ for s_ in prod if "debug" in s_]
+    assert _lib.DEBUG_LIB_PATH.exists(), "build with `python -m quantizedsae_amd.build`"
+    dbg = {s_ for s_ in build.exported_symbols(_lib.DEBUG_LIB_PATH) if s_.startswith("qsae_")}
+    assert declared <= dbg and any(s_.startswith("qsae_debug_") for s_ in dbg)
+    with _lib.use_library("debug") as lib:
+        assert lib.qsae_abi_version() == 2 and _lib.load() is lib
+    assert _lib.load() is not lib
 
 
 def test_host_side_entry_points():

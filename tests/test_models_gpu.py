@@ -71,6 +71,108 @@ def test_binary_sae(name):
     assert np.array_equal(host(recon_c), recon)
 
 
+@pytest.mark.parametrize("name", ["binary_soft_small", "binary_soft_init", "binary_soft_n8", "binary_soft_mid"])
+def test_binary_sae_unpolarised_checkpoints_follow_the_reference_forward(name):
+    """Checkpoints whose decoder logits are not saturated (N(0, s^2) logits, the reference's default init): the
+    reference forward multiplies with the soft sigmoid-bit integers (sae/binary.py:24-47).  decode_mode='auto' (the
+    default) notices at pack time (soft_gap) and reproduces the reference's reconstructions to 1e-5; the explicit
+    'hard' mode is the packed two's-complement decode and is far from them on such a checkpoint."""
+    fx = Fixture(name)
+    m, sd = fx.meta, fx.state_dict()
+    rows = m["rows"]
+    x = fx.x()[:rows]
+    model = load(BinarySAE(m["D"], m["H"], gamma=m["gamma"], n_bits=m["n_bits"]), sd)
+    model.k = m["k"] / m["H"]
+    assert model.decoder.decode_mode == "auto"
+    with pytest.warns(UserWarning, match="not polarised"):
+        latent, recon, pol = model(dev(x))
+    assert model.decoder.resolved_decode_mode() == "soft"
+    assert model.decoder.packed()["soft_gap"] == pytest.approx(float(fx["soft_gap"]), rel=1e-4)
+    latent, recon = host(latent), host(recon)
+    want = oracle.binary_forward(x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                 sd["decoder.bias"], n_bits=m["n_bits"], gamma=m["gamma"], k=m["k"], soft=True)
+    assert np.array_equal(latent, want["latent"])                       # the encoder side is exact as ever
+    assert rel_err(recon, want["reconstruction"]) < RECON_TOL           # (expf of the device vs the host's)
+    nz = latent != 0
+    idx_sorted = np.stack([np.nonzero(r)[0] for r in nz]).astype(np.int32)
+    same = audit_topk_sets(fx, idx_sorted)
+    assert row_rel_err(recon, fx["reconstruction"])[same].max() < RECON_TOL
+    assert float(pol) == pytest.approx(float(fx["polarize_loss"]), rel=2e-5)
+    if "soft_int_weights" in fx:
+        assert np.max(np.abs(host(model.decoder.quantized_int_weights_continuous()) - fx["soft_int_weights"])) \
+            < 2.0 ** (m["n_bits"] - 22)
+        assert np.array_equal(host(model.decoder.quantized_int_weights()), fx["int_weights"].astype(np.float32))
+        # the dense entry point of the decoder (reference signature) follows the same choice
+        rec_d, _ = model.decoder(dev(fx["sparse_latent"]), None)
+        assert rel_err(host(rec_d), fx["reconstruction"]) < RECON_TOL
+    # compact path and explicit modes
+    idx, val, recon_c = model.forward_compact(dev(x))
+    assert np.array_equal(host(recon_c), recon)
+    model.decoder.decode_mode = "soft"
+    assert np.array_equal(host(model(dev(x))[1]), recon)
+    model.decoder.decode_mode = "hard"
+    hard = oracle.binary_forward(x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"],
+                                 sd["decoder.bias"], n_bits=m["n_bits"], gamma=m["gamma"], k=m["k"])
+    rec_h = host(model(dev(x))[1])
+    assert np.array_equal(rec_h, hard["reconstruction"])
+    assert row_rel_err(rec_h, fx["reconstruction"])[same].max() > 1e-2
+
+
+def test_binary_auto_mode_takes_the_packed_decode_on_polarised_checkpoints():
+    """+-30 logits: soft_gap ~1e-12, auto == hard (bit for bit), no warning; +-12 logits: gap 1e-4 -> soft."""
+    import warnings
+    fx = Fixture("binary_small")
+    m, sd = fx.meta, fx.state_dict()
+    model = load(BinarySAE(m["D"], m["H"], gamma=m["gamma"], n_bits=m["n_bits"]), sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, rec_auto, _ = model(dev(fx.x()))
+    assert model.decoder.resolved_decode_mode() == "hard" and model.decoder.packed()["soft_gap"] < 1e-9
+    model.decoder.decode_mode = "hard"
+    assert torch.equal(model(dev(fx.x()))[1], rec_auto)
+    model.decoder.decode_mode = "auto"
+    with torch.no_grad():
+        model.decoder.weight.mul_(12.0 / 30.0)                  # version bump: repacked, gap re-measured
+    with pytest.warns(UserWarning, match="not polarised"):
+        model(dev(fx.x()))
+    assert 1e-5 < model.decoder.packed()["soft_gap"] < 1e-3 and model.decoder.resolved_decode_mode() == "soft"
+
+
+def test_binary_k_zero_and_limits():
+    """hidden_dim < 500 -> k = int(H * 0.002) = 0: the reference's topk(0) keeps nothing (zero latent, bias-only
+    reconstruction, sae/binary.py:94-99); limits of the kernels are reported as ValueError, not as a HIP error."""
+    m = BinarySAE(64, 400, gamma=4.0, n_bits=4).to(DEV).eval()
+    with torch.no_grad():
+        m.decoder.bias.copy_(torch.arange(64, device=DEV) * 0.25)
+        m.decoder.weight.copy_(torch.where(torch.rand_like(m.decoder.weight) > 0.5, 30.0, -30.0))
+    assert m.top_k == 0
+    x = torch.randn(5, 64, device=DEV)
+    lat, rec, pol = m(x)
+    assert lat.shape == (5, 400) and not lat.any()
+    assert torch.equal(rec, m.decoder.bias.detach().expand(5, -1))
+    idx, val, rec_c = m.forward_compact(x)
+    assert idx.shape == (5, 0) and torch.equal(rec_c, rec)
+    m2 = BinarySAE(64, 1024, gamma=4.0, n_bits=4).to(DEV).eval()
+    m2.k = 0.3                                                  # 307 > 256
+    with pytest.raises(ValueError, match="limit of 256"):
+        m2(torch.randn(4, 64, device=DEV))
+
+
+def test_invalidate_packed_after_data_edit():
+    """In-place edits through .data bump no version counter (the reference's own ternary code edits weights that way):
+    invalidate_packed() is the documented way to make the model repack."""
+    m = BinarySAE(64, 1024, gamma=4.0, n_bits=4).to(DEV).eval()
+    m.decoder.decode_mode = "hard"
+    x = torch.randn(8, 64, device=DEV)
+    m.decoder.weight.data.copy_(torch.where(torch.rand_like(m.decoder.weight) > 0.5, 30.0, -30.0))
+    m.invalidate_packed()
+    r1 = m(x)[1].clone()
+    m.decoder.weight.data.mul_(-1.0)                            # flips every bit, invisibly to the cache
+    assert torch.equal(m(x)[1], r1)                             # ... which therefore still decodes the old dictionary
+    m.invalidate_packed()
+    assert not torch.equal(m(x)[1], r1)
+
+
 def test_binary_decoder_dense_entry_and_exports():
     fx = Fixture("binary_small")
     m, sd = fx.meta, fx.state_dict()

@@ -53,6 +53,37 @@ def test_binary_forward_matches_reference(name):
         assert mse == pytest.approx(float(fx["mse"]), rel=1e-5)
 
 
+@pytest.mark.parametrize("name", ["binary_soft_small", "binary_soft_init", "binary_soft_n8", "binary_soft_mid"])
+def test_binary_soft_forward_matches_reference(name):
+    """Unpolarised checkpoints: the reference forward IS the soft sigmoid-bit computation (sae/binary.py:24-47).  The
+    oracle's soft restatement reproduces its reconstructions to 1e-5; the hard-bit decode of the same checkpoint does
+    not (that is what decode_mode='auto' exists for), and the packer's soft_gap says so."""
+    fx = Fixture(name)
+    m = fx.meta
+    sd = fx.state_dict()
+    rows = m["rows"]
+    x = fx.x()[:rows]
+    kw = dict(n_bits=m["n_bits"], gamma=m["gamma"], k=m["k"])
+    args = (x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"], sd["decoder.bias"])
+    soft = oracle.binary_forward(*args, soft=True, **kw)
+    _check_topk_sets(fx, soft["idx"])
+    ok_rows = (np.sort(soft["idx"], axis=1) == fx["topk_idx"]).all(axis=1)
+    assert ok_rows.any()
+    errs = row_rel_err(soft["reconstruction"], fx["reconstruction"])
+    assert errs[ok_rows].max() < RECON_TOL, errs.max()
+    assert soft["polarize_loss"] == pytest.approx(float(fx["polarize_loss"]), rel=2e-5)
+    gap = oracle.soft_gap(sd["decoder.weight"], m["D"], m["n_bits"])
+    assert gap == pytest.approx(float(fx["soft_gap"]), rel=1e-5) and gap > 0.3      # far from polarised
+    if "soft_int_weights" in fx:
+        table = oracle.soft_table(sd["decoder.weight"], m["D"], m["n_bits"])
+        # (summation order of the n bit terms: an ulp or two at the table's magnitude, 2^(n-1))
+        assert np.max(np.abs(table - fx["soft_int_weights"])) < 2.0 ** (m["n_bits"] - 22)
+        assert np.array_equal(oracle.unpack_binary(oracle.pack_binary(sd["decoder.weight"], m["D"], m["n_bits"]), m["D"],
+                                                   m["n_bits"]), fx["int_weights"].astype(np.float32))
+    hard = oracle.binary_forward(*args, soft=False, **kw)
+    assert row_rel_err(hard["reconstruction"], fx["reconstruction"])[ok_rows].max() > 1e-2
+
+
 @pytest.mark.parametrize("name", ["baseline_small", "baseline_mid", "baseline_full"])
 def test_baseline_forward_matches_reference(name):
     fx = Fixture(name)

@@ -6,7 +6,7 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from quantizedsae_amd import BinarySAE, _lib, ops
-lib = _lib.load()
+lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
 lib.qsae_debug_set_fill_co.argtypes = [C.c_int]
 dev = "cuda:0"
 D, H, B = 512, 32768, 65536

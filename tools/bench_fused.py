@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from quantizedsae_amd import _lib, ops  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
 lib.qsae_debug_set_stagger.argtypes = [C.c_int]
 B, D, H, k = 65536, 512, 32768, 65
 x = torch.randn(B, D, device="cuda:0")

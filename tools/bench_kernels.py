@@ -43,7 +43,7 @@ def main():
     a = ap.parse_args()
     B, H, D, k = a.B, a.H, a.D, a.k
     dev = "cuda:0"
-    lib = _lib.load()
+    lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
     lib.qsae_debug_set_gemm_config.argtypes = [C.c_int]
     lib.qsae_debug_set_sweep.argtypes = [C.c_int]
     lib.qsae_debug_set_topk_path.argtypes = [C.c_int]

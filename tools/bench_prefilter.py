@@ -19,7 +19,7 @@ x = torch.randn(B, D, device="cuda:0")
 W = (torch.rand(H, D, device="cuda:0") * 2 - 1) * (6.0 / (D + H)) ** 0.5
 bias = torch.zeros(H, device="cuda:0")
 Wq, meta = ops.prefilter_pack_w(W, bias)
-lib = _lib.load()
+lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
 lib.qsae_debug_set_prefilter_tile.argtypes = [C.c_int]
 lib.qsae_debug_set_xstat_rot.argtypes = [C.c_int]
 lib.qsae_debug_set_refine_ablate.argtypes = [C.c_int]
@@ -47,12 +47,13 @@ for rnd in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ops.sweep_timing(True)
         e0.record()
+        info = {}
         for _ in range(3):
-            ops.encode_topk_prefilter(x, W, bias, Wq, meta, k, want_dense=dense)
+            ops.encode_topk_prefilter(x, W, bias, Wq, meta, k, want_dense=dense, info=info)
         e1.record(); e1.synchronize()
         ops.sweep_timing(False)
         ms, n, frac = ops.sweep_timing_collect(H)
-        res.setdefault((dense, tile, rot), []).append((ms, e0.elapsed_time(e1) / 3, lib.qsae_debug_last_flagged()))
+        res.setdefault((dense, tile, rot), []).append((ms, e0.elapsed_time(e1) / 3, info.get("flagged_rows", -1)))
 lib.qsae_debug_set_prefilter_tile(2)
 lib.qsae_debug_set_xstat_rot(2)
 lib.qsae_debug_set_refine_ablate(0)

@@ -54,8 +54,11 @@ def topk_gap(latent: np.ndarray, k: int) -> np.ndarray:
 
 # ---------------------------------------------------------------------------
 def gen_binary(ref, name, seed, D, H, B, n_bits, gamma, k=None, store_inputs=False, rows=None,
-               enc_bias_std=0.0, dec_bias_std=0.0):
-    sd = S.binary_sae_params(seed, D, H, n_bits, enc_bias_std=enc_bias_std, dec_bias_std=dec_bias_std)
+               enc_bias_std=0.0, dec_bias_std=0.0, logit_std=None):
+    """logit_std: unpolarised decoder logits (the reference forward then differs from a hard-bit decode: it IS the soft
+    sigmoid-bit computation, binary.py:24-47); the fixture also stores the soft integer table."""
+    sd = S.binary_sae_params(seed, D, H, n_bits, enc_bias_std=enc_bias_std, dec_bias_std=dec_bias_std,
+                             logit_std=logit_std)
     x = S.activations(seed, B, D)
     model = ref.BinarySAE(D, H, gamma=gamma, n_bits=n_bits)
     load_sd(model, sd)
@@ -66,6 +69,7 @@ def gen_binary(ref, name, seed, D, H, B, n_bits, gamma, k=None, store_inputs=Fal
         sparse_latent, recon, pol = model(t(x))
         latent_full = model.encode(t(x)).numpy()
         int_w = model.decoder.quantized_int_weights().numpy()
+        soft_w = model.decoder.quantized_int_weights_continuous().numpy()
     sparse_latent = sparse_latent.numpy()
     # index set of the kept entries, straight from torch.topk inside the reference
     with torch.no_grad():
@@ -75,16 +79,36 @@ def gen_binary(ref, name, seed, D, H, B, n_bits, gamma, k=None, store_inputs=Fal
     meta = dict(variant="binary", seed=seed, D=D, H=H, B=B, n_bits=n_bits, gamma=gamma, k=kk,
                 rows=(B if rows is None else rows), logit_mag=30.0, enc_bias_std=enc_bias_std,
                 dec_bias_std=dec_bias_std, torch=torch.__version__)
+    if logit_std is not None:
+        meta["logit_std"] = logit_std
     arrays = dict(topk_idx=np.sort(idxs.numpy()[r], axis=1).astype(np.int32),
                   topk_val_sorted_by_idx=np.take_along_axis(vals.numpy()[r], np.argsort(idxs.numpy()[r], axis=1), axis=1),
                   gap=topk_gap(latent_full, kk)[r],
                   reconstruction=recon.numpy()[r], polarize_loss=np.float64(pol.item()),
                   mse=np.float64(mse))
+    if logit_std is not None:
+        arrays.update(soft_gap=np.float64(np.abs(soft_w - int_w).max()))
+        if H * D <= 1 << 17:
+            arrays.update(soft_int_weights=soft_w.astype(np.float32))
     if store_inputs:
         arrays.update(x=x, **{"sd." + k_: v for k_, v in sd.items() if k_ != "decoder.weight"},
-                      dec_bits=np.packbits((sd["decoder.weight"] > 0).astype(np.uint8), axis=1),
+                      dec_bits=np.packbits((int_w.astype(np.int64)[..., None] >> np.arange(n_bits) & 1).astype(np.uint8)
+                                           .reshape(H, D * n_bits), axis=1),
                       int_weights=int_w.astype(np.int8), sparse_latent=sparse_latent)
     save(name, meta, **arrays)
+
+
+def gen_binary_soft(ref):
+    """Unpolarised BinarySAE checkpoints: N(0, 2^2) logits, the reference's default (kaiming) decoder init, and a
+    mid-size model at logit std 1 -- outputs of the reference forward, which uses the soft sigmoid bits."""
+    gen_binary(ref, "binary_soft_small", seed=16, D=64, H=1000, B=7, n_bits=4, gamma=4.0, store_inputs=True,
+               enc_bias_std=0.05, dec_bias_std=0.2, logit_std=2.0)
+    gen_binary(ref, "binary_soft_init", seed=17, D=64, H=1000, B=7, n_bits=4, gamma=4.0, store_inputs=True,
+               logit_std=float(np.sqrt(2.0 / (64 * 4))))
+    gen_binary(ref, "binary_soft_n8", seed=19, D=32, H=512, B=5, n_bits=8, gamma=1.5, k=3, store_inputs=True,
+               dec_bias_std=0.2, logit_std=3.0)
+    gen_binary(ref, "binary_soft_mid", seed=18, D=512, H=2048, B=32, n_bits=4, gamma=4.0, k=65,
+               enc_bias_std=0.05, dec_bias_std=0.2, logit_std=1.0)
 
 
 def gen_baseline(ref, name, seed, D, H, B, store_inputs=False, rows=None, bias_std=0.0):
@@ -202,6 +226,8 @@ def gen_sigmoid_cutoffs():
 def main():
     ref = load_reference()
     only = set(sys.argv[1:])
+    if only == {"binary_soft"}:
+        return gen_binary_soft(ref)
     if only and not (only & {"binary", "baseline", "ternary"}):
         return main_tail(ref, only)
     print("sigmoid cutoffs")
@@ -216,6 +242,7 @@ def main():
                enc_bias_std=0.05, dec_bias_std=0.2)
     gen_binary(ref, "binary_full_g4", seed=1, D=512, H=32768, B=256, n_bits=4, gamma=4.0)
     gen_binary(ref, "binary_full_g15", seed=1, D=512, H=32768, B=64, n_bits=4, gamma=1.5)
+    gen_binary_soft(ref)
     print("baseline")
     gen_baseline(ref, "baseline_small", seed=21, D=64, H=1000, B=7, store_inputs=True, bias_std=0.1)
     gen_baseline(ref, "baseline_mid", seed=22, D=512, H=2048, B=32, bias_std=0.1)

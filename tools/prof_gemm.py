@@ -13,7 +13,7 @@ from quantizedsae_amd import _lib, ops  # noqa: E402
 B, D, H = 65536, 512, 32768
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3").split(",")]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-lib = _lib.load()
+lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
 lib.qsae_debug_set_gemm_config.argtypes = [C.c_int]
 x = torch.randn(B, D, device="cuda:0")
 W = (torch.rand(H, D, device="cuda:0") * 2 - 1) * (6.0 / (D + H)) ** 0.5

@@ -15,7 +15,7 @@ x = torch.randn(B, D, device="cuda:0")
 W = (torch.rand(H, D, device="cuda:0") * 2 - 1) * (6.0 / (D + H)) ** 0.5
 bias = torch.zeros(H, device="cuda:0")
 Wq, meta = ops.prefilter_pack_w(W, bias)
-lib = _lib.load()
+lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
 lib.qsae_debug_set_prefilter_tile.argtypes = [C.c_int]
 lib.qsae_debug_set_xstat_stamps.argtypes = [C.c_void_p]
 stamps = torch.zeros((B // 256, 8, 8), dtype=torch.int64, device="cuda:0")

@@ -15,7 +15,7 @@ acc = torch.zeros((), dtype=torch.float64, device=dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 ts, out = [], []
 import os
-lib = _lib.load()
+lib = _lib.use_library("debug").__enter__()   # tools run against libqsae_hip_debug.so (qsae_debug_* switches)
 if os.environ.get('QSAE_FILL_CO') is not None:
     lib.qsae_debug_set_fill_co.argtypes = [C.c_int]
     lib.qsae_debug_set_fill_co(int(os.environ['QSAE_FILL_CO']))
@@ -36,7 +36,7 @@ with torch.no_grad():
         if i >= 5:
             ts.append(dt)
             if dt > 6.0:
-                out.append(dict(step=i, wall_ms=round(dt, 3), gpu_ms=round(e0.elapsed_time(e1), 3), flagged=int(lib.qsae_debug_last_flagged())))
+                out.append(dict(step=i, wall_ms=round(dt, 3), gpu_ms=round(e0.elapsed_time(e1), 3), flagged=int(model.last_flagged_rows)))
 for o in out:
     print(json.dumps(o))
 ts.sort()
