@@ -753,7 +753,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
             const uint2 c = seg[i];
             const float v = __uint_as_float(c.x);
             const uint32_t kk = mono_key(v);
-            any_nan |= (v != v);
+            any_nan |= (v != v) || c.y >= static_cast<uint32_t>(H);     // (a hidden index outside the dictionary: never gather with it)
             all_or |= kk;
             all_and &= kk;
             lkey[filled + i] = kk;
