@@ -35,18 +35,30 @@ BYTES_PER_ROW_DENSE = 4 * D + 4 * H + 4 * D             # 135 168 B per row, den
 PEAK_FP32_MFMA_TFLOPS = 157.3                           # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBPS = 8000.0                                  # HBM3E, MI355X_MICROARCH.md
 PEAK_FP16_MFMA_TFLOPS = 2500.0                          # dense (the ~5 PF headline figure includes 2:1 sparsity)
+WEIGHT_BYTES_PER_BATCH = 4 * H * D + 4 * H + (H * D * N_BITS) // 8 + 4 * D      # 75 630 592 B
+
+
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")      # newest first
+TRAFFIC_SOURCE = None
 
 
 def pmc_traffic(key):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
-    command, FETCH_SIZE doubled per the gfx950 correction).  bench.py cannot profile itself; the
-    number is quoted only for the kernel/shape it was collected on, otherwise null."""
-    try:
-        doc = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
-        return doc["kernels"][key]["hbm_side_bytes_per_launch"]
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    (profiles/rNN_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same
+    command, FETCH_SIZE doubled per the gfx950 correction).  bench.py cannot profile itself: this is a
+    STATIC figure (see `traffic_source` in the output), quoted only for the kernel/shape it was collected
+    on, otherwise null."""
+    global TRAFFIC_SOURCE
+    for name in TRAFFIC_FILES:
+        try:
+            doc = json.load(open(ROOT / "profiles" / name))
+            val = doc["kernels"][key]["hbm_side_bytes_per_launch"]
+            TRAFFIC_SOURCE = (f"static: profiles/{name} (rocprofv3 --pmc passes of this command on an MI355X, FETCH_SIZE x2 per the "
+                              "gfx950 correction); not measured during this run")
+            return val
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def build_model(device, seed=1):
@@ -97,7 +109,12 @@ def cpu_baseline(model, x_sample, max_threads):
                 break
     except OSError:
         pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
     return {"value": xs.shape[0] / best, "unit": "activations/s", "cores": threads, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "host_cpus_in_affinity_mask": affinity,
             "sample": f"{xs.shape[0]} rows of the same batch and weights, torch-CPU op-sequence restatement of "
                       f"BinarySAE.forward (oracle/torch_restatement.py), fp32, best of {reps} runs over intra-op thread counts up to {max_threads} "
                       f"(best at {threads}), host CPU: {cpu_name}"}
@@ -114,19 +131,26 @@ def secondary_configs(device, x):
     def run(name, model, call, rows, flops_per_row):
         model = model.to(device).eval()
         xb = x[:rows]
+        reps = 10
         with torch.no_grad():
             for _ in range(2):
                 r = call(model, xb)
             torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
             t0 = time.perf_counter()
-            for _ in range(3):
+            for a, b in evs:                                  # one event pair per repetition, on the launch stream
+                a.record()
                 r = call(model, xb)
+                b.record()
             torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 3 * 1e3
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        gpu = sorted(a.elapsed_time(b) for a, b in evs)
+        ms = gpu[reps // 2]
         del r, model
         torch.cuda.empty_cache()
-        out.append({"config": name, "rows": rows, "ms_per_step": ms, "activations_per_s": rows / ms * 1e3,
-                    "algorithmic_tflops": flops_per_row * rows / ms / 1e9})
+        out.append({"config": name, "rows": rows, "ms_per_step": ms, "ms_min": gpu[0], "ms_max": gpu[-1],
+                    "ms_wall_mean": wall, "reps": reps, "timing": "HIP events per repetition, median",
+                    "activations_per_s": rows / ms * 1e3, "algorithmic_tflops": flops_per_row * rows / ms / 1e9})
 
     B = x.shape[0]
     with torch.no_grad():
@@ -173,6 +197,9 @@ def main():
     ap.add_argument("--latent-path", default="auto", choices=["auto", "fused", "inplace", "prefilter"])
     ap.add_argument("--no-fp32-reference", action="store_true", help="skip the extra fp32-only measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (rank 0, N=1 only)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="batches in flight: 2 = submit step i+1 before finishing step i (qsae_prefilter_submit / _finish: "
+                         "the 4-byte flagged-row read-back of a step no longer idles the GPU); 1 = blocking forward()")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,6 +238,23 @@ def main():
         ops.sq_err_sum(recon, x, acc)
         return latent, recon
 
+    def run_steps(n_steps, acc):
+        """n_steps full forwards + MSE accumulation.  With --pipeline 2 step i+1's kernels are queued before step i's
+        flagged-row count is read (every step still completes inside the caller's timed region)."""
+        if args.pipeline <= 1:
+            for _ in range(n_steps):
+                step(acc)
+            return
+        pending = None
+        for i in range(n_steps):
+            h = model.forward_submit(x, slot=i % 2)
+            if pending is not None:
+                _lat, rec, _pol = pending.result()
+                ops.sq_err_sum(rec, x, acc)
+            pending = h
+        _lat, rec, _pol = pending.result()
+        ops.sq_err_sum(rec, x, acc)
+
     def timed_region(n_steps, acc):
         """barrier + sync, n_steps forwards, sync + barrier; returns elapsed seconds (max over ranks) and
         the live HIP-event timing of the dominant sweep kernel."""
@@ -221,8 +265,7 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for _ in range(n_steps):
-            step(acc)
+        run_steps(n_steps, acc)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -232,8 +275,8 @@ def main():
         sweep = ops.sweep_timing_collect(H)
         return sharding.max_over_ranks(dt, device=device), sweep
 
-    for _ in range(args.warmup):
-        step(torch.zeros((), dtype=torch.float64, device=device))
+    if args.warmup > 0:
+        run_steps(args.warmup, torch.zeros((), dtype=torch.float64, device=device))
     elapsed, (sweep_ms, sweep_n, sweep_frac) = timed_region(args.steps, sq)
     mse = sharding.reduce_mse(sq, args.steps * B * D)
     path_used = model.resolved_latent_path(B)
@@ -299,7 +342,7 @@ def main():
                                    "polarize loss) + recon-MSE accumulation",
                        "rows_per_gpu": B, "input_dim": D, "hidden_dim": H, "n_bits": N_BITS, "gamma": GAMMA,
                        "top_k": K_TOP, "parallelism": f"row-sharded x{world}, no data-path collective",
-                       "latent_path": path_used,
+                       "latent_path": path_used, "batches_in_flight": args.pipeline,
                        "precision_note": ("every returned value (latent, reconstruction, MSE) is exact fp32 and bit-identical "
                                           "to the fp32-only path; with latent_path='prefilter' an fp16 MFMA pass with a rigorous "
                                           "per-row error bound only selects ~80 candidate hidden units per row, which are then "
@@ -315,6 +358,16 @@ def main():
                          "traffic": pmc_traffic(tkey) if (tkey and B == ROWS_PER_GPU) else None},
             "fp32_only_path": fp32_ref,
         }
+        # the whole step against the HBM roofline: SURVEY 8(d) bytes per row (x in, dense latent + reconstruction out) plus
+        # the weights once per batch, over the step time the driver also sees
+        step_bytes = BYTES_PER_ROW_DENSE * B + WEIGHT_BYTES_PER_BATCH
+        step_ms = elapsed / args.steps * 1e3
+        out["roofline"]["whole_step"] = {
+            "bound": "hbm", "algorithmic_bytes_per_step": step_bytes, "ms_per_step": step_ms,
+            "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            "frac_of_achievable_6300": step_bytes / (step_ms * 1e-3) / 1e9 / 6300.0}
+        out["roofline"]["traffic_source"] = TRAFFIC_SOURCE
         if path_used == "prefilter" and sweep_n and enc_ms:
             # The sweep / fill pair carries two resources: 2.06 PFLOP of fp16 MFMA (0.82 ms at peak) and the 8.6 GB of
             # zeros of the dense latent (1.07 ms at 8 TB/s).  The second one binds, so it is the roofline quoted first;

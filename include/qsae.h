@@ -277,6 +277,19 @@ int qsae_decode_matryoshka_sparse(const uint32_t* zbits, int64_t words_ld, int B
 int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, float thr, uint32_t* zbits,
                       int64_t words_ld, qsae_stream_t stream);
 
+/* -- small elementwise steps (each operation rounded separately, as in the reference's ATen sequence) -------- */
+/* out[i] = (residual[i] - recon[i]) * scale: the residual handed to the next stage of ResidualQuantizedSAE
+ * (sae/residual_quantized.py:67, scale = 2).  out may alias residual. */
+int qsae_residual_update(const float* residual, const float* recon, size_t n, float scale, float* out,
+                         qsae_stream_t stream);
+/* out[i] = pre[i] >= cutoff ? 1 : 0: the binary latent of BinaryLatentSAE, sigmoid(pre) >= 0.5 <=> pre >= 0xB43FFFFE
+ * (sae/binary_latent.py:21-24). */
+int qsae_threshold_ge(const float* pre, size_t n, float cutoff, float* out, qsae_stream_t stream);
+/* out[b][d] = scale * acc[b][d] + bias[d] (bias may be NULL): the tail of binary_decoder.forward on an arbitrary dense
+ * latent, reconstruction = quantization_step * latent.matmul(int_weights) + bias (sae/binary.py:38). */
+int qsae_scale_bias_rows(const float* acc, int B, int D, float scale, const float* bias, float* out,
+                         qsae_stream_t stream);
+
 /* -- metric ------------------------------------------------------------------------------ */
 /* *sum += sum_i (float)((recon[i]-x[i])^2) accumulated in double (device pointer; the caller
  * zeroes it).  scripts/analysis/dynamic_analysis.py:86-100. */

@@ -304,8 +304,12 @@ def matryoshka_forward(x, enc_w, enc_b, dec_w, dec_wm, dec_bias, *, n_bits: int,
     zb = zbits(pre)
     codes, scale = matryoshka_pack(dec_w, dec_wm, n_bits, abs_range)
     levels, l0 = decode_matryoshka(zb, codes, scale, dec_bias, n_bits, allow_bias)
+    gt, _ge = sigmoid_cutoffs()
+    # per row: how close the nearest pre-activation comes to the `latent > 0.5` cutoff (a bit that another summation
+    # order of the encoder could flip); used by the tests' near-cutoff audit
+    dist = np.min(np.abs(pre.astype(np.float64) - np.float64(gt)), axis=1)
     return {"zbits": zb, "latent_groups": l0, "reconstruction_levels": levels,
-            "reconstruction": levels[-1]}
+            "reconstruction": levels[-1], "cutoff_distance": dist}
 
 
 def residual_forward(x, stages, *, abs_range: float):
@@ -313,15 +317,20 @@ def residual_forward(x, stages, *, abs_range: float):
     dicts(enc_w, enc_b, dec_w, dec_wm, dec_bias); each stage is a 1-bit matryoshka SAE,
     bias only in stage 0; residual = (residual - recon) * 2."""
     residual = np.ascontiguousarray(x, dtype=np.float32)
-    groups, levels = [], []
+    groups, levels, dist = [], [], []
     for i, st in enumerate(stages):
         out = matryoshka_forward(residual, st["enc_w"], st["enc_b"], st["dec_w"], st["dec_wm"],
                                  st["dec_bias"], n_bits=1, abs_range=abs_range, allow_bias=(i == 0))
         groups.append(out["latent_groups"][-1])
         levels.append(out["reconstruction"])
+        dist.append(out["cutoff_distance"])
         residual = ((residual - out["reconstruction"]).astype(np.float32) * np.float32(2)).astype(np.float32)
+    # cutoff_distance[i][b]: nearest pre-activation of stage i, row b, to the cutoff.  A row whose stages 0..i all stay
+    # clear of it has the same bits under any summation order of the encoder, hence the same level-i output up to
+    # rounding; a row that does not may legitimately differ by one dictionary row times 2^i (residuals are doubled).
     return {"latent_groups": np.asarray(groups, dtype=np.float32),
-            "reconstruction_levels": np.stack(levels), "reconstruction": levels[-1]}
+            "reconstruction_levels": np.stack(levels), "reconstruction": levels[-1],
+            "cutoff_distance": np.stack(dist)}
 
 
 # ---- consumers of the sparse latent (scripts/analysis/dynamic_analysis.py:255-311) -------------------------

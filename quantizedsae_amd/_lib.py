@@ -69,6 +69,9 @@ SIGNATURES = {
     "qsae_pack_matryoshka_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "qsae_decode_matryoshka_sparse": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_pack_bits_gt": (_i, [_vp, _i64, _i, _i, _f, _vp, _i64, _vp]),
+    "qsae_residual_update": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
+    "qsae_threshold_ge": (_i, [_vp, _sz, _f, _vp, _vp]),
+    "qsae_scale_bias_rows": (_i, [_vp, _i, _i, _f, _vp, _vp, _vp]),
     "qsae_sq_err_sum": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "qsae_activation_counts": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "qsae_activation_counts_bits": (_i, [_vp, _i64, _i, _i, _vp, _vp]),

@@ -134,6 +134,40 @@ pack_bits_gt_kernel(const float* __restrict__ dense, int64_t ld, int B, int H, f
     zbits[b * words_ld + wi] = word;
 }
 
+// ---- small elementwise steps of the forward paths (one pass over HBM each; separately rounded operations, as the
+// reference's ATen sequence rounds them) ----------------------------------------------------------------------
+// mode 0: out = (a - b) * scale           residual = (residual - reconstruction) * 2, sae/residual_quantized.py:67
+// mode 1: out = a >= cutoff ? 1 : 0       binary latent of BinaryLatentSAE (sigmoid(pre) >= 0.5), sae/binary_latent.py:21-24
+// mode 2: out = scale * a + bias[i % D]   reconstruction = step * latent.matmul(int_w) + bias, sae/binary.py:38
+__global__ void __launch_bounds__(256)
+elementwise_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int mode, float scale, int D,
+                   float* __restrict__ out) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v;
+        if (mode == 0) {
+            v = a[i] - b[i];
+            v = v * scale;
+        } else if (mode == 1) {
+            v = a[i] >= scale ? 1.0f : 0.0f;
+        } else {
+            v = scale * a[i];
+            v = v + (b ? b[i % static_cast<size_t>(D)] : 0.0f);
+        }
+        out[i] = v;
+    }
+}
+
+static int launch_elementwise(const float* a, const float* b, size_t n, int mode, float scale, int D, float* out,
+                              hipStream_t s) {
+    if (n == 0) return QSAE_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(elementwise_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, b, n, mode, scale, D, out);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
 // scatter without the preceding zero fill (the fused encoder zero-fills the dense latent itself)
 int scatter_rows(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld, hipStream_t s);
 
@@ -193,6 +227,27 @@ extern "C" int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, f
                        ld, B, H, thr, zbits, words_ld, words);
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
+}
+
+extern "C" int qsae_residual_update(const float* residual, const float* recon, size_t n, float scale, float* out,
+                                    qsae_stream_t stream) {
+    if (n == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(residual && recon && out, "null pointer");
+    return launch_elementwise(residual, recon, n, 0, scale, 1, out, as_stream(stream));
+}
+
+extern "C" int qsae_threshold_ge(const float* pre, size_t n, float cutoff, float* out, qsae_stream_t stream) {
+    if (n == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(pre && out, "null pointer");
+    return launch_elementwise(pre, nullptr, n, 1, cutoff, 1, out, as_stream(stream));
+}
+
+extern "C" int qsae_scale_bias_rows(const float* acc, int B, int D, float scale, const float* bias, float* out,
+                                    qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0, "B >= 0 and D > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(acc && out, "null pointer");
+    return launch_elementwise(acc, bias, static_cast<size_t>(B) * D, 2, scale, D, out, as_stream(stream));
 }
 
 extern "C" int qsae_abi_version(void) { return QSAE_ABI_VERSION; }

@@ -165,9 +165,12 @@ def _load_state_dict(entry: SAERegistryEntry) -> Dict[str, torch.Tensor]:
         return torch.load(entry.checkpoint_path, map_location="cpu", weights_only=True)
     if entry.checkpoint_format == "safetensors":
         if load_safetensors is None:
-            raise ImportError("safetensors is required to load baseline SAE checkpoints; "
-                              "install it with `pip install safetensors`.")
-        state = load_safetensors(str(entry.checkpoint_path))
+            # no `safetensors` package: the package's own reader (framework.py:236-260 falls back to the reference's
+            # pure-python reader the same way; ours lives in quantizedsae_amd/load_baseline.py)
+            from ..load_baseline import load_safetensors as local_loader
+            state = local_loader(str(entry.checkpoint_path))
+        else:
+            state = load_safetensors(str(entry.checkpoint_path))
         return state if "encoder.0.weight" in state else _remap_eleuther(state)
     raise ValueError(f"Unsupported checkpoint format '{entry.checkpoint_format}' for SAE '{entry.name}'.")
 

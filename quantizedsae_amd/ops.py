@@ -608,6 +608,38 @@ def pack_bits_gt(dense: torch.Tensor, thr: float) -> torch.Tensor:
     return z
 
 
+# ---- small elementwise steps ---------------------------------------------------------------------
+@_on_tensor_device
+def residual_update(residual: torch.Tensor, recon: torch.Tensor, scale: float = 2.0) -> torch.Tensor:
+    """(residual - recon) * scale, each operation rounded separately (sae/residual_quantized.py:67)."""
+    residual, recon = _f32c(residual, "residual"), _f32c(recon, "recon")
+    if residual.shape != recon.shape:
+        raise ValueError("residual and recon must have the same shape")
+    out = torch.empty_like(residual)
+    check(_lib.load().qsae_residual_update(_p(residual), _p(recon), residual.numel(), float(scale), _p(out), _stream()))
+    return out
+
+
+@_on_tensor_device
+def threshold_ge(pre: torch.Tensor, cutoff: float) -> torch.Tensor:
+    """1.0 where pre >= cutoff else 0.0 (sae/binary_latent.py:21-24 with the fp32 cutoff of sigmoid >= 0.5)."""
+    pre = _f32c(pre, "pre")
+    out = torch.empty_like(pre)
+    check(_lib.load().qsae_threshold_ge(_p(pre), pre.numel(), float(cutoff), _p(out), _stream()))
+    return out
+
+
+@_on_tensor_device
+def scale_bias_rows(acc: torch.Tensor, scale: float, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """scale * acc + bias over the rows of a [B, D] tensor, multiply and add rounded separately (sae/binary.py:38)."""
+    acc = _f32c(acc, "acc")
+    B, D = acc.shape
+    b = _f32c(bias, "bias") if bias is not None else None
+    out = torch.empty_like(acc)
+    check(_lib.load().qsae_scale_bias_rows(_p(acc), B, D, float(scale), _p(b), _p(out), _stream()))
+    return out
+
+
 # ---- metric ------------------------------------------------------------------------------------
 @_on_tensor_device
 def sq_err_sum(recon: torch.Tensor, x: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:

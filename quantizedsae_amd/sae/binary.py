@@ -105,7 +105,7 @@ class binary_decoder(nn.Module):
             st = self.packed()
             table = self.soft_table() if self.resolved_decode_mode() == "soft" else self._int_table()
             acc = ops.encode_dense(latent, table.t().contiguous(), None, ops.ACT_NONE)
-            recon = self.quantization_step * acc + self.bias.detach()
+            recon = ops.scale_bias_rows(acc, self.quantization_step, self.bias.detach())
             return recon, st["polarize"]
 
     def _int_table(self) -> torch.Tensor:

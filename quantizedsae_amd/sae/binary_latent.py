@@ -29,7 +29,7 @@ class BinaryLatentSAE(SparseAutoencoder):
             lin = self.encoder.linear
             pre = ops.encode_dense(x if x.dtype == torch.float32 else x.float(), lin.weight.detach(), lin.bias.detach(),
                                    ops.ACT_NONE)
-            binary_latent = (pre >= _GE_HALF_CUTOFF).float()
+            binary_latent = ops.threshold_ge(pre, _GE_HALF_CUTOFF)
             recon = ops.encode_dense(binary_latent, self.decoder.weight.detach(), self.decoder.bias.detach(),
                                      ops.ACT_NONE)
             return binary_latent, recon

@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .base import SparseAutoencoder, require_device_input
 from .quantized_matryoshka import QuantizedMatryoshkaSAE, nested_sizes
 
@@ -37,7 +38,7 @@ class ResidualQuantizedSAE(SparseAutoencoder):
                 g, recs = sae(residual)
                 groups.append(g[-1])
                 levels.append(recs[-1])
-                residual = (residual - recs[-1]) * 2
+                residual = ops.residual_update(residual, recs[-1], 2.0)          # (residual - reconstruction) * 2
             return groups, levels
 
     def apply_secant_grad(self):

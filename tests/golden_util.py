@@ -82,6 +82,17 @@ def row_rel_err(a: np.ndarray, ref: np.ndarray) -> np.ndarray:
     return np.max(np.abs(a - ref), axis=-1) / np.maximum(np.max(np.abs(ref), axis=-1), 1e-30)
 
 
+# near-cutoff audit for the threshold activations (`latent > 0.5`, sae/quantized_matryoshka.py:97-99): the reference's
+# sgemm moves a pre-activation by <= ~4e-6 against the fmaf chain; a row all of whose units stay further than this from
+# the cutoff has the same bits under either summation order.
+NEAR_CUTOFF_EPS = 2e-5
+
+
+def residual_clear_rows(cutoff_distance: np.ndarray, level: int) -> np.ndarray:
+    """Rows whose stages 0..level all keep every pre-activation clear of the cutoff (oracle.residual_forward)."""
+    return (cutoff_distance[: level + 1] > NEAR_CUTOFF_EPS).all(axis=0)
+
+
 # near-tie audit threshold for top-k index-set parity against the reference (SURVEY.md section 7):
 # the reference's sgemm summation order moves a latent by <= ~7e-7 at sigma ~0.18; rows whose
 # k/(k+1) gap is below NEAR_TIE_EPS may legitimately select a different boundary element.

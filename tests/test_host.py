@@ -187,6 +187,58 @@ def test_eleuther_safetensors_remap(tmp_path):
     BaselineSparseAutoencoder(D, H).load_state_dict(sd, strict=True)
 
 
+def test_pure_python_safetensors_reader_and_loader_fallback(tmp_path, monkeypatch):
+    """quantizedsae_amd/load_baseline.py (reference data/load_baseline.py:5-53) against files written by the real
+    `safetensors` package, and the loader's branch for hosts without that package (framework.py:236-260)."""
+    import dataclasses
+    import json
+    import struct
+    from safetensors.torch import load_file, save_file
+    from quantizedsae_amd.load_baseline import load_safetensors as local
+    H, D = 48, 16
+    g = torch.Generator().manual_seed(3)
+    raw = {"encoder.weight": torch.randn(H, D, generator=g), "encoder.bias": torch.randn(H, generator=g),
+           "W_dec": torch.randn(H, D, generator=g), "b_dec": torch.randn(D, generator=g),
+           "half": torch.randn(5, 3, generator=g).half(), "bf": torch.randn(7, generator=g).bfloat16(),
+           "i64": torch.arange(6).reshape(2, 3), "i32": torch.arange(4, dtype=torch.int32), "u8": torch.arange(9, dtype=torch.uint8),
+           "flag": torch.tensor([True, False, True]), "scalar": torch.tensor(2.5), "empty": torch.zeros((0, 4))}
+    path = tmp_path / "sae.safetensors"
+    save_file(raw, str(path), metadata={"format": "pt"})
+    got, want = local(path), load_file(str(path))
+    assert set(got) == set(want) == set(raw)
+    for k in raw:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape and torch.equal(got[k], want[k]), k
+    got["encoder.bias"] += 1.0                                            # the result owns writable memory
+    # the loader without the safetensors package: same remapped state dict as with it
+    entry = dataclasses.replace(F.SAE_REGISTRY["baseline_sae"], checkpoint_path=path, checkpoint_format="safetensors",
+                                kwargs={"input_dim": D, "hidden_dim": H})
+    with_pkg = F._load_state_dict(entry)
+    monkeypatch.setattr(F, "load_safetensors", None)
+    without = F._load_state_dict(entry)
+    assert list(without) == list(with_pkg) == ["encoder.0.weight", "encoder.0.bias", "decoder.weight", "decoder.bias"]
+    assert all(torch.equal(without[k], with_pkg[k]) for k in with_pkg)
+    assert without["decoder.weight"].shape == (D, H) and without["decoder.weight"].is_contiguous()
+    BaselineSparseAutoencoder(D, H).load_state_dict(without, strict=True)
+    # malformed files are refused, not reinterpreted
+    def write(hdr, payload=b"", n=None):
+        h = json.dumps(hdr).encode()
+        q = tmp_path / "bad.safetensors"
+        q.write_bytes(struct.pack("<Q", len(h) if n is None else n) + h + payload)
+        return q
+    for bad in (write({"a": {"dtype": "F32", "shape": [2], "data_offsets": [0, 8]}}, b"\0" * 4),       # payload too short
+                write({"a": {"dtype": "F32", "shape": [3], "data_offsets": [0, 8]}}, b"\0" * 8),       # shape x dtype != bytes
+                write({"a": {"dtype": "F8_E4M3", "shape": [8], "data_offsets": [0, 8]}}, b"\0" * 8),   # unknown dtype
+                write({"a": {"dtype": "F32", "shape": [2]}}, b"\0" * 8),                               # no offsets
+                write({}, n=1 << 40)):                                                                 # absurd header length
+        with pytest.raises(ValueError):
+            local(bad)
+    short = tmp_path / "short.safetensors"
+    short.write_bytes(b"\x01\x02")
+    with pytest.raises(ValueError):
+        local(short)
+    assert local(write({"__metadata__": {"k": "v"}})) == {}
+
+
 # ---- sharding ------------------------------------------------------------------------------------------
 def test_shard_rows_partitions_exactly():
     for n in [0, 1, 7, 64, 65536, 10_000_000, 10_000_001]:

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from golden_util import Fixture, NEAR_TIE_EPS, rel_err, row_rel_err
+from golden_util import Fixture, NEAR_TIE_EPS, rel_err, residual_clear_rows, row_rel_err
 
 RECON_TOL = 1e-5   # north_star: within 1e-5 relative on fp32 reconstructions
 
@@ -100,12 +100,19 @@ def test_baseline_forward_matches_reference(name):
         assert np.max(np.abs(out["latent"] - fx["sparse_latent"])) < 4e-6
 
 
-@pytest.mark.parametrize("name", ["ternary_small", "ternary_mid"])
+@pytest.mark.parametrize("name", ["ternary_small", "ternary_mid", "ternary_full"])
 def test_ternary_forward_matches_reference(name):
     fx = Fixture(name)
     sd = fx.state_dict()
     out = oracle.ternary_forward(fx.x(), sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"])
     assert float(fx["nonzero_code_fraction"]) > 0.2          # fixture exercises non-zero codes
+    if fx["latent"].shape != out["latent"].shape:            # full-size fixture: first rows + per-row digests of the dense latent
+        rows = fx["latent"].shape[0]
+        assert np.max(np.abs(out["latent"][:rows] - fx["latent"])) < 4e-6
+        assert np.abs((out["latent"] > 0).sum(1) - fx["latent_nnz"]).max() <= 2     # (a latent within 1e-6 of zero may flip)
+        np.testing.assert_allclose(out["latent"].astype(np.float64).sum(1), fx["latent_sum"], rtol=1e-6)
+        assert rel_err(out["reconstruction"], fx["reconstruction"]) < RECON_TOL
+        return
     assert np.max(np.abs(out["latent"] - fx["latent"])) < 4e-6
     assert np.array_equal(out["latent"] > 0, fx["latent"] > 0) or \
         np.abs(fx["latent"][(out["latent"] > 0) != (fx["latent"] > 0)]).max() < 1e-6
@@ -129,8 +136,12 @@ def test_matryoshka_forward_matches_reference(name):
         assert rel_err(out["reconstruction_levels"][lvl], fx["reconstruction_levels"][lvl]) < RECON_TOL, lvl
 
 
-@pytest.mark.parametrize("name", ["residual_small", "residual_mid"])
+@pytest.mark.parametrize("name", ["residual_small", "residual_mid", "residual_full"])
 def test_residual_forward_matches_reference(name):
+    """Stage i binarises `sigmoid(encoder(residual)) > 0.5`: a pre-activation within summation-order noise of the cutoff
+    may come out on the other side in the reference (sgemm) than in the fmaf chain, and the flipped dictionary row is then
+    carried, doubled, through every later stage.  Audit instead of a blanket tolerance: rows whose stages 0..i all stay
+    clear of the cutoff (oracle cutoff_distance > 2e-5) must match at 1e-5; the others stay within one flipped row."""
     fx = Fixture(name)
     m = fx.meta
     sd = fx.state_dict()
@@ -139,8 +150,15 @@ def test_residual_forward_matches_reference(name):
                    dec_bias=sd[f"saes.{i}.decoder.bias"]) for i in range(m["n_bits"])]
     out = oracle.residual_forward(fx.x(), stages, abs_range=m["abs_range"])
     np.testing.assert_allclose(out["latent_groups"], fx["latent_groups"], rtol=2e-3)
+    n_clear = 0
     for lvl in range(m["n_bits"]):
-        assert rel_err(out["reconstruction_levels"][lvl], fx["reconstruction_levels"][lvl]) < 5e-4, lvl
+        clear = residual_clear_rows(out["cutoff_distance"], lvl)
+        errs = row_rel_err(out["reconstruction_levels"][lvl], fx["reconstruction_levels"][lvl])
+        if clear.any():
+            assert errs[clear].max() < RECON_TOL, (lvl, errs[clear].max())
+        assert errs.max() < 5e-3, lvl
+        n_clear += int(clear.sum())
+    assert n_clear > 0                                                  # the audit is not vacuous
 
 
 def test_sigmoid_cutoffs_pinned():

@@ -133,7 +133,8 @@ def gen_baseline(ref, name, seed, D, H, B, store_inputs=False, rows=None, bias_s
     save(name, meta, **arrays)
 
 
-def gen_ternary(ref, name, seed, D, H, B, store_inputs=False):
+def gen_ternary(ref, name, seed, D, H, B, store_inputs=False, latent_rows=None):
+    """latent_rows: store only the first rows of the dense [B, H] latent (full-size fixture) plus per-row digests."""
     sd = S.ternary_sae_params(seed, D, H)
     x = S.activations(seed, B, D)
     model = ref.TernarySparseAutoencoder(D, H)
@@ -141,7 +142,9 @@ def gen_ternary(ref, name, seed, D, H, B, store_inputs=False):
     with torch.no_grad():
         h, recon = model(t(x))
     meta = dict(variant="ternary", seed=seed, D=D, H=H, B=B, w_std=0.5, torch=torch.__version__)
-    arrays = dict(latent=h.numpy(), reconstruction=recon.numpy(),
+    hn = h.numpy()
+    arrays = dict(latent=hn if latent_rows is None else hn[:latent_rows], reconstruction=recon.numpy(),
+                  latent_nnz=(hn > 0).sum(1).astype(np.int32), latent_sum=hn.astype(np.float64).sum(1),
                   nonzero_code_fraction=np.float64((np.abs(sd["decoder.weight"]) >= 0.5).mean()))
     if store_inputs:
         arrays.update(x=x, **{"sd." + k_: v for k_, v in sd.items() if k_ != "decoder.mask"})
@@ -228,6 +231,9 @@ def main():
     only = set(sys.argv[1:])
     if only == {"binary_soft"}:
         return gen_binary_soft(ref)
+    if only == {"full"}:
+        gen_ternary(ref, "ternary_full", seed=2, D=512, H=32768, B=32, latent_rows=2)
+        return gen_residual(ref, "residual_full", seed=53, D=512, H=32768, B=16, n_bits=4, abs_range=1.5)
     if only and not (only & {"binary", "baseline", "ternary"}):
         return main_tail(ref, only)
     print("sigmoid cutoffs")
@@ -250,6 +256,7 @@ def main():
     print("ternary")
     gen_ternary(ref, "ternary_small", seed=31, D=64, H=1000, B=7, store_inputs=True)
     gen_ternary(ref, "ternary_mid", seed=32, D=512, H=2048, B=16)
+    gen_ternary(ref, "ternary_full", seed=2, D=512, H=32768, B=32, latent_rows=2)
     main_tail(ref, only)
 
 
@@ -304,6 +311,7 @@ def main_tail(ref, only):
     print("residual")
     gen_residual(ref, "residual_small", seed=51, D=64, H=1024, B=7, n_bits=4, abs_range=1.5, store_inputs=True)
     gen_residual(ref, "residual_mid", seed=52, D=512, H=4096, B=8, n_bits=4, abs_range=1.5)
+    gen_residual(ref, "residual_full", seed=53, D=512, H=32768, B=16, n_bits=4, abs_range=1.5)
 
 
 if __name__ == "__main__":
