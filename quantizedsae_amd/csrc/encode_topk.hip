@@ -87,8 +87,10 @@ static int pilot_width(int H) {
     return p;
 }
 
+constexpr int kFusedSplit = 4;     // exact fp32 sweep: workgroups per activation panel (hidden range in quarters, see run_fused)
+
 struct FusedLayout {
-    size_t pilot, tau, cnt, cand, flags, fx, flat, fidx, fval, total;
+    size_t pilot, tau, cnt, cnt_split, cand, flags, fx, flat, fidx, fval, total;
 };
 
 static FusedLayout fused_layout(int B, int D, int H, int k) {
@@ -98,6 +100,7 @@ static FusedLayout fused_layout(int B, int D, int H, int k) {
     L.pilot = off; off = align_up(off + static_cast<size_t>(B) * P * 4, 256);
     L.tau = off;   off = align_up(off + static_cast<size_t>(B) * 4, 256);
     L.cnt = off;   off = align_up(off + static_cast<size_t>(B) * 4, 256);
+    L.cnt_split = off; off = align_up(off + static_cast<size_t>(B) * 4 * (kFusedSplit - 1), 256);   // list-segment counters of slices 1..
     L.cand = off;  off = align_up(off + static_cast<size_t>(B) * kCandCap * 8, 256);
     L.flags = off; off = align_up(off + (static_cast<size_t>(B) + 4) * 4, 256);     // [0] = count, then row ids
     L.fx = off;    off = align_up(off + static_cast<size_t>(kChunkRows) * D * 4, 256);
@@ -129,6 +132,11 @@ struct EpiFilter {
         int64_t dense_ld;    //   here (the k survivors are scattered in afterwards); nullptr = no dense output
         const float* inv;    // APPROX: [B] 1 / (row scale * weight scale), a power of two
         const float* margin; // APPROX: [B] 2 * eps_b
+        // The hidden range may be split over `parts` workgroups per activation panel (SweepMap::msplit, TileCtx::part):
+        // slice p appends to segment [p * cap / parts, (p + 1) * cap / parts) of every row's list and counts in
+        // cnt (p == 0, which also holds the pilot's seeds) or cnt_parts[(p - 1) * rows + row].  parts <= 1: one segment.
+        int parts = 1;
+        int* cnt_parts = nullptr;
     };
     float tau[NT];
     float inv[NT];
@@ -138,7 +146,7 @@ struct EpiFilter {
         int* counters = reinterpret_cast<int*>(c.lds_epi);
         if (c.tid < BN) {
             const int row = c.n0 + c.tid;
-            counters[c.tid] = row < c.N ? a.cnt[row] : 0;
+            counters[c.tid] = (row < c.N && c.part == 0) ? a.cnt[row] : 0;
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -199,7 +207,8 @@ struct EpiFilter {
         for (int nt = 0; nt < NT; ++nt) {
             const int lcol = c.wn * WTN + nt * 32 + c.lane_col;
             const float t = tau[nt];
-            uint2* list = a.cand + static_cast<int64_t>(c.n0 + lcol) * a.cap;
+            const int cap_part = a.parts > 1 ? a.cap / a.parts : a.cap;
+            uint2* list = a.cand + static_cast<int64_t>(c.n0 + lcol) * a.cap + (a.parts > 1 ? c.part * cap_part : 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -209,7 +218,7 @@ struct EpiFilter {
                         const int h = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
                         if (h < c.M && col_ok[nt]) {
                             const int pos = atomicAdd(&counters[lcol], 1);
-                            if (pos < a.cap)
+                            if (pos < cap_part)
                                 list[pos] = make_uint2(__float_as_uint(v), static_cast<uint32_t>(h + a.hidden_offset));
                         }
                     }
@@ -221,7 +230,8 @@ struct EpiFilter {
         const int* counters = reinterpret_cast<const int*>(c.lds_epi);
         if (c.tid < BN) {
             const int row = c.n0 + c.tid;
-            if (row < c.N) a.cnt[row] = counters[c.tid];
+            int* dst = (a.parts > 1 && c.part > 0) ? a.cnt_parts + static_cast<int64_t>(c.part - 1) * c.N : a.cnt;
+            if (row < c.N) dst[row] = counters[c.tid];
         }
     }
 };
@@ -232,14 +242,35 @@ constexpr int kSelSlots = kCandCap / 64;   // candidates per lane
 
 __global__ void __launch_bounds__(64 * kSelWaves)
 select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, int B, int H, int k,
-                   int32_t* __restrict__ idx_out, float* __restrict__ val_out, int* __restrict__ flags) {
+                   int32_t* __restrict__ idx_out, float* __restrict__ val_out, int* __restrict__ flags, int parts,
+                   const int* __restrict__ cnt_parts) {
     __shared__ unsigned long long sel[kSelWaves][256];
     __shared__ unsigned short sel_src[kSelWaves][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * kSelWaves + wave;
     if (b >= B) return;
-    const int n = cnt[b];
-    if (n < k || n > cap) {                       // tau not a lower bound, or list overflow
+    // the row's list is `parts` segments of cap / parts entries (one per hidden-range slice of the sweep); seg_end[p] =
+    // candidates in segments 0..p
+    static_assert(kFusedSplit <= 4, "segment bookkeeping below is written for up to four segments");
+    const int cap_part = cap / parts;
+    int seg_end[4];
+    bool seg_overflow = false;
+    int n = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int np = p >= parts ? 0 : (p == 0 ? cnt[b] : cnt_parts[static_cast<int64_t>(p - 1) * B + b]);
+        seg_overflow |= np > cap_part;
+        n += np;
+        seg_end[p] = n;
+    }
+    // candidate number i (0 <= i < n, segments in order) -> its slot in the row's list
+    const int e0 = seg_end[0], e1 = seg_end[1], e2 = seg_end[2];      // (named: no runtime-indexed local array)
+    auto slot_of = [&](int i) {
+        const int p = (i >= e0 ? 1 : 0) + (i >= e1 ? 1 : 0) + (i >= e2 ? 1 : 0);
+        const int first = i >= e2 ? e2 : (i >= e1 ? e1 : (i >= e0 ? e0 : 0));
+        return p * cap_part + (i - first);
+    };
+    if (n < k || n > cap || seg_overflow) {       // tau not a lower bound, or list overflow
         if (lane == 0) {
             const int slot = atomicAdd(&flags[0], 1);
             flags[1 + slot] = b;
@@ -253,7 +284,7 @@ select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     for (int s = 0; s < kSelSlots; ++s) {
         const int i = s * 64 + lane;
         if (i < n) {
-            const uint2 c = list[i];
+            const uint2 c = list[slot_of(i)];
             key[s] = (static_cast<unsigned long long>(mono_key(__uint_as_float(c.x))) << 16) |
                      static_cast<unsigned long long>((H - 1) - static_cast<int>(c.y));
         } else {
@@ -306,7 +337,7 @@ select_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         const unsigned long long kj = mine[j];
         int rank = 0;
         for (int i = 0; i < k; ++i) rank += (mine[i] > kj) ? 1 : 0;
-        const uint2 c = list[src[j]];               // raw value bits and index of the survivor
+        const uint2 c = list[slot_of(src[j])];      // raw value bits and index of the survivor
         idx_out[static_cast<int64_t>(b) * k + rank] = static_cast<int32_t>(c.y);
         val_out[static_cast<int64_t>(b) * k + rank] = __uint_as_float(c.x);
     }
@@ -487,6 +518,8 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     rc = topk_rows_dispatch(pilot, P, B, P, j, nullptr, nullptr, 0, tau, cand, cnt, kCandCap, dense, dense_ld, s);
     if (rc != QSAE_OK) return rc;
     // 2. sweep of the remaining hidden units with the threshold filter (R = W rows, Cm = x rows)
+    int split = 1;                                           // hidden-range slices per activation panel (list segments)
+    int* cnt_split = reinterpret_cast<int*>(ws + L.cnt_split);
     {
         constexpr int BM = 128, BN = 128, BK = 32;
         using Epi = EpiFilter<BM, BN>;
@@ -494,9 +527,18 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
         const int Hs = H - P;
         if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
         if (kperm && g_sweep_kernel == 0 && D % kDmaBK == 0) {
+            // One workgroup per (activation panel, quarter of the hidden range) instead of one per panel: the block map
+            // deals the four workgroups of a panel to the same XCD next to each other, so an XCD's 32 resident workgroups
+            // share 8 panels (2 MiB: they stay in its 4 MiB L2 for the whole sweep) instead of owning 32 (8 MiB: every
+            // panel was re-fetched for every hidden tile -- 3.1x the algorithmic traffic, profiles/r01_traffic.json).
+            // Each quarter appends to its own segment of the rows' candidate lists.
             using EpiD = EpiFilter<256, 128, 4, 2>;
-            typename EpiD::Args ed{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, nullptr, nullptr};
-            rc = launch_gemm_dma<EpiD, 256, 128>(W + static_cast<size_t>(P) * D, Hs, x, B, D, ed, s);
+            const int tiles = (Hs + 255) / 256;
+            split = (tiles >= 4 * kFusedSplit && B >= 4096) ? kFusedSplit : 1;
+            typename EpiD::Args ed{bias ? bias + P : nullptr, tau, cand, cnt, kCandCap, P, dense, dense_ld, nullptr, nullptr,
+                                   split, cnt_split};
+            rc = launch_gemm_dma<EpiD, 256, 128>(W + static_cast<size_t>(P) * D, Hs, x, B, D, ed, s,
+                                                 split > 1 ? (tiles + split - 1) / split : 0);
         } else if (kperm) {
             using LA = LoaderF32<BM, BK, false, true, true>;
             using LB = LoaderF32<BN, BK, false, true, true>;
@@ -521,7 +563,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
     }
     // 3. exact selection among the candidates
     hipLaunchKernelGGL(select_topk_kernel, dim3((B + kSelWaves - 1) / kSelWaves), dim3(64 * kSelWaves), 0, s, cand, cnt,
-                       kCandCap, B, H, k, idx, val, flags);
+                       kCandCap, B, H, k, idx, val, flags, split, cnt_split);
     QSAE_LAUNCH_CHECK();
     // 4. flagged rows (normally none): one 4-byte read-back, then the unfused kernels on those rows
     const FlaggedArgs fa{x, W, bias, B, D, H, k, idx, val, ws, L, stream, kperm, nullptr, 0};

@@ -321,6 +321,7 @@ struct TileCtx {
     int lane_half;     // lane >> 5  -> +4 on the output row
     int M, N, K;
     int tid;
+    int part;          // which of the map's msplit slices of the R range this workgroup sweeps (0 when it sweeps all of it)
     float* lds_epi;    // epilogue scratch (kLdsFloats floats), after the staging buffers
 };
 
@@ -355,6 +356,7 @@ gemm_nt_f32_kernel(typename LA::Args la, typename LB::Args lb, typename Epi::Arg
     ctx.M = M; ctx.N = N; ctx.K = K; ctx.tid = tid;
     ctx.lds_epi = smem + 2 * (TILE_A + TILE_B);
     ctx.m0 = m_first * BM;
+    ctx.part = m_first / map.sweep;
 
     // Two workgroups share a CU and run the same program: launched together they reach their
     // barriers and LDS-write phases together and leave the matrix pipe idle together.  Blocks are

@@ -62,6 +62,7 @@ gemm_nt_f32_dma_kernel(const float* __restrict__ Rp, int M, const float* __restr
     ctx.M = M; ctx.N = N; ctx.K = K; ctx.tid = tid;
     ctx.lds_epi = smem + STAGES * STAGE;
     ctx.m0 = m_first * BM;
+    ctx.part = m_first / map.sweep;
 
     Epi epi;
     epi.begin(ea, ctx);

@@ -627,3 +627,29 @@ def test_prefilter_degenerate_rows_fall_back(fused_path):
     assert torch.equal(idx2, idx) and torch.equal(val2.view(torch.int32), val.view(torch.int32))
     if dense is not None:
         assert torch.equal(dense2.view(torch.int32), dense.view(torch.int32))
+
+
+def test_ablation_builds_of_the_encoder_run_clean_at_the_shape_that_once_faulted():
+    """Round 1, 18:15-18:20: `tools/bench_ablate.py` (B=32768, D=512, H=16384) ended twice in a GPU memory-access fault
+    (gpurun_out/abl3.log: address 0x3bf3daf5c000; abl4.log: address nil).  Cause: the ablated
+    instantiations (no loads / no LDS traffic inside the K loop) had been built on top of the then-new inline-asm staging
+    loads, whose completion only the complete pipeline waits for; the two prologue load sets were still in flight when the
+    registers were reused, and a late 16-byte load landed in a register pair that by then held an address.  Since 15326ec
+    ablated builds use compiler-visible loads.  This runs the three builds once at that shape in the debug library (the
+    product library has neither the entry point nor the ablated kernels); build 0 must equal the product encoder."""
+    from quantizedsae_amd import _lib
+    ops = _ops()
+    B, D, H = 32768, 512, 16384
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    x = torch.randn((B, D), device=DEV, generator=g)
+    W = (torch.rand((H, D), device=DEV, generator=g) * 2 - 1) * 0.0134
+    want = ops.encode_dense(x, W, None)
+    out = torch.empty((B, H), device=DEV)
+    with _lib.use_library("debug") as lib:
+        f = lib.qsae_debug_encode_ablate
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for ablate in (1, 2, 0):
+            assert f(x.data_ptr(), W.data_ptr(), B, D, H, out.data_ptr(), 2, ablate, stream) == 0
+            torch.cuda.synchronize()
+    assert torch.equal(out, want)                              # the last build run (0) is the complete pipeline
