@@ -19,6 +19,7 @@
 //   4. fallback: ... and flagged rows (normally none) are recomputed by the unfused kernels.
 // Small problems use the chunked two-kernel form directly.
 #include <vector>
+#include <type_traits>
 
 #include "gemm_mfma_f32.h"
 #include "gemm_mfma_f32_dma.h"
@@ -69,6 +70,8 @@ QSAE_TUNABLE g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16
 QSAE_TUNABLE_PTR g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
 QSAE_TUNABLE g_ref_ablate = 0;       // timing experiments on the refine kernel (results wrong when non-zero)
 QSAE_TUNABLE g_xstat_ablate = 0;     // timing experiments only (results are wrong when non-zero)
+QSAE_TUNABLE g_x_phase = 3;          // experiment: bit 0 = run x prep + sweep (+ fill), bit 1 = run the refinement
+QSAE_TUNABLE g_x_parts = 0;          // experiment: hidden-range parts of the stationary sweep (0 = xstat_parts)
 QSAE_TUNABLE g_pref_tile = 2;        // fp16 sweep: 2 = activation-stationary kernel (where supported), 0 = 256 x 256 tile
                                      // (2 stages), 1 = 256 x 128 tile (3 stages)
 
@@ -601,7 +604,8 @@ static PrefLayout pref_layout(int B, int D, size_t base) {
     return P;
 }
 
-// meta (device float[4]): [0] sw (power-of-two weight scale), [1] max_h ||W_h||_2, [2] max|bias|, [3] max|W|
+// meta (device float[4]): [0] sw (power-of-two weight scale), [1] max_h ||W_h||_2, [2] max|bias|, [3] max|W| while
+// packing, afterwards max_h ||W_h - W^_h||_2 (the distance of the fp16 copy, pref_w_err_kernel)
 __global__ void __launch_bounds__(256)
 pref_w_stats_kernel(const float* __restrict__ W, const float* __restrict__ bias, int H, int D, unsigned* __restrict__ meta) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -635,6 +639,24 @@ pref_w_cast_kernel(const float* __restrict__ W, long long n, float* __restrict__
     if (gid < n) Wq[gid] = static_cast<_Float16>(W[gid] * sw);       // exact scaling, one RNE rounding
 }
 
+// one wave per hidden unit: distance between the row and its fp16 copy as the matrix core reads it
+__global__ void __launch_bounds__(256)
+pref_w_err_kernel(const float* __restrict__ W, int H, int D, const float* __restrict__ sw_ptr, unsigned* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= H) return;
+    const float sw = *sw_ptr;
+    if (!(sw > 0.f)) return;                                        // non-finite weights: every row is flagged anyway
+    const float back = 1.0f / sw;
+    float ff = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float w = W[static_cast<int64_t>(row) * D + d];
+        const float e = fp16_input_error(w, w * sw, back);
+        ff = fmaf(e, e, ff);
+    }
+    for (int off = 32; off > 0; off >>= 1) ff += __shfl_xor(ff, off, 64);
+    if (lane == 0) atomicMax(out, __float_as_uint(sqrtf(ff) * 1.0001f));
+}
+
 // one wave per activation row: fp16 copy scaled by a per-row power of two, 1/(sx*sw), margin = 2*eps_b
 __global__ void __launch_bounds__(256)
 pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ meta,
@@ -654,9 +676,18 @@ pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __res
         mx = (o > mx || o != o) ? o : mx;
         ss += __shfl_xor(ss, off, 64);
     }
+    // second pass over the row (L1 / L2 hits): the fp16 copy and its distance from the row
+    const float sx0 = pow2_scale_for(mx), back = sx0 > 0.f ? 1.0f / sx0 : 0.f;
+    float ee = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = xr[d];
+        xq[static_cast<int64_t>(row) * D + d] = static_cast<_Float16>(v * sx0);
+        const float e = fp16_input_error(v, v * sx0, back);
+        ee = fmaf(e, e, ee);
+    }
+    for (int off = 32; off > 0; off >>= 1) ee += __shfl_xor(ee, off, 64);
     float sx, iv, mg;
-    pref_row_params(mx, ss, D, meta[0], meta[1], meta[2], sx, iv, mg);
-    for (int d = lane; d < D; d += 64) xq[static_cast<int64_t>(row) * D + d] = static_cast<_Float16>(xr[d] * sx);
+    pref_row_params(mx, ss, ee, D, meta[0], meta[1], meta[2], meta[3], sx, iv, mg);
     if (lane == 0) {
         inv[row] = iv;
         margin[row] = mg;
@@ -731,7 +762,10 @@ __host__ __device__ static inline size_t ref_lds_per_wave(int) {
     return static_cast<size_t>(kRefMaxSurv) * 8 + 64 * kRefTileStride * 4 + kRefMaxSurv * 4;
 }
 
-__global__ void __launch_bounds__(64 * kRefWaves)
+// kAbl (debug library only, results wrong): 3 = no scalar loads of the activation row, 4 = no LDS transpose, 5 = no
+// gathers in the main loop, 6 = 3 + 4
+template <bool kCounted, int kAbl = 0>
+__global__ void __launch_bounds__(64 * kRefWaves, 3)            // three workgroups per CU: <= 168 registers
 refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
                    const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
                    const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
@@ -868,34 +902,44 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         const int j = j0 + lane;
         const int h = (j < m) ? hidx[j] : hidx[j0];
         float acc = bias ? bias[h] : 0.0f;
-        // row pointers of the 8 line-loads this lane takes part in: rows 8i + lane/8 of the group
-        const float* rp[8];
+        // rows of the 8 line-loads this lane takes part in: rows 8i + lane/8 of the group, as byte offsets into W
+        // (32 bits in the counted form -- the launcher checks 4 H D < 2^32 --, which is also 8 registers less)
+        typename std::conditional<kCounted, uint32_t, int64_t>::type voff[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int jj = j0 + 8 * i + (lane >> 3);
             jj = jj < m ? jj : j0;
-            rp[i] = W + static_cast<int64_t>(ablate == 1 ? (lane >> 3) : hidx[jj]) * D + 4 * (lane & 7);
+            const int row = ablate == 1 ? (lane >> 3) : hidx[jj];
+            if (kCounted) voff[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
+            else voff[i] = static_cast<int64_t>(row) * (D * 4) + 16 * (lane & 7);
         }
+        const char* wbase = reinterpret_cast<const char*>(W);
+        auto visible_load = [&](f32x4 (&sv)[8], int blk) {     // loads the compiler sees (and waits for by its own count)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const f32x4*>(wbase + voff[i] + 128 * blk);
+        };
         f32x4 st[kRefSets][8];
-#pragma unroll
-        for (int q = 0; q < kRefSets; ++q)
-            if (q < nblk) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * q);
-            }
         auto consume = [&](const f32x4 (&sv)[8], int t) {
             f32x4 xv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xv[q] = xrow[8 * t + q];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
-            lds_handoff();
-            const float* mine = wt + lane * kRefTileStride;
+            for (int q = 0; q < 8; ++q) {
+                if (kAbl == 3 || kAbl == 6) xv[q] = f32x4{tau_b, margin_b, tau_b, margin_b};
+                else xv[q] = xrow[8 * t + q];
+            }
             f32x4 w[8];
+            if (kAbl == 4 || kAbl == 6) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
-            lds_handoff();
+                for (int q = 0; q < 8; ++q) w[q] = sv[q];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+                lds_handoff();
+                const float* mine = wt + lane * kRefTileStride;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
+                lds_handoff();
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 acc = fmaf(xv[q][0], w[q][0], acc);
@@ -904,16 +948,61 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                 acc = fmaf(xv[q][3], w[q][3], acc);
             }
         };
-        for (int t = 0; t < nblk; t += kRefSets) {
+        int t = 0;
+        if (kCounted) {
+            // Counted form (nblk >= kRefSets).  The compiler's own wait counting gives up on this loop: with the refills
+            // inside it, it puts vmcnt(0) in front of the first block of every round, so each round waits for the set
+            // issued LAST at full latency -- about one set in flight per wave instead of kRefSets.  Here the loads of
+            // the prologue and of the main loop are inline asm (invisible to that bookkeeping; base in SGPRs, 32-bit
+            // lane offsets) and so are the waits: loads retire in issue order, set q is always followed by exactly
+            // kRefSets - 1 younger sets, so vmcnt(8 (kRefSets - 1)) in front of a block means "this set has landed".
+            // The wait statement names the set's registers as read-write operands: every use of the data depends on
+            // it.  The refills are unconditional (main loop: rounds whose refills all exist), so no value defined by an
+            // asm load meets another definition at a join (a copy there would read the register before the data lands).
+            auto issue = [&](f32x4 (&sv)[8], int blk) {
+                const char* sb = wbase + 128 * blk;             // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv[i]) : "v"(voff[i]), "s"(sb));
+            };
+            auto landed = [&](f32x4 (&sv)[8]) {
+                static_assert(kRefSets == 2 || kRefSets == 3, "wait counts below");
+                if (kRefSets == 3)
+                    asm volatile("s_waitcnt vmcnt(16)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]),
+                                 "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
+                else
+                    asm volatile("s_waitcnt vmcnt(8)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]),
+                                 "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
+            };
+            // the loads the compiler does know about (the bias) have to be retired in front of the asm loads: its wait
+            // for them would otherwise sit at the first use inside the loop, as vmcnt(0), in every round
+            asm volatile("" : "+v"(acc));
+#pragma unroll
+            for (int q = 0; q < kRefSets; ++q) issue(st[q], q);
+            for (; t + 2 * kRefSets <= nblk; t += kRefSets) {
+#pragma unroll
+                for (int q = 0; q < kRefSets; ++q) {
+                    if (kAbl != 5) landed(st[q]);
+                    consume(st[q], t + q);
+                    if (kAbl != 5) issue(st[q], t + q + kRefSets);
+                }
+            }
+            // everything issued so far has to land before the last rounds (their refills are ordinary loads again)
+#pragma unroll
+            for (int q = 0; q < kRefSets; ++q)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[q][0]), "+v"(st[q][1]), "+v"(st[q][2]), "+v"(st[q][3]),
+                             "+v"(st[q][4]), "+v"(st[q][5]), "+v"(st[q][6]), "+v"(st[q][7]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < kRefSets; ++q)
+                if (q < nblk) visible_load(st[q], q);
+        }
+        for (; t < nblk; t += kRefSets) {
 #pragma unroll
             for (int q = 0; q < kRefSets; ++q) {
                 if (t + q < nblk) {
                     consume(st[q], t + q);
-                    if (t + q + kRefSets < nblk) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + q + kRefSets));
-                    }
+                    if (t + q + kRefSets < nblk) visible_load(st[q], t + q + kRefSets);
                 }
             }
         }
@@ -927,6 +1016,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     }
     lds_handoff();
     stamp(4);
+    if (ablate == 2) return;           // (timing experiment without the chains: the keys below were never written -- no outputs)
     // ---- exact rank among the survivors ----------------------------------------------------------------
     // (with a decoder attached the winners are also kept in LDS, in the W tile's space, which is free by now)
     int* w_idx = reinterpret_cast<int*>(wt);
@@ -1085,7 +1175,7 @@ static PrefPlan pref_plan(const PrefCall& c) {
     p.hoff = p.inkernel ? 0 : p.P;
     // small batches: the hidden range of the sweep is split over `parts` workgroup columns, each with its own
     // segment of every row's candidate list
-    p.parts = p.xstat ? xstat_parts(c.B, p.Hs, kCandCap) : 1;
+    p.parts = p.xstat ? (g_x_parts > 0 ? g_x_parts : xstat_parts(c.B, p.Hs, kCandCap)) : 1;
     p.cap_part = kCandCap / p.parts;
     p.fill_co = p.xstat && c.dense && g_fill_co && c.D == 512 && c.H % 256 == 0 && c.dense_ld % 4 == 0 && g_xstat_ablate == 0 &&
                 co_fill_fits();
@@ -1129,7 +1219,7 @@ static int prefilter_submit(const PrefCall& c) {
     // 1. fp16 copy of the batch + per-row scale and error margin (the stationary sweep with the in-kernel pilot can do
     //    this in its own prologue, straight into registers)
     const bool fuse_prep = inkernel && g_fuse_xprep;
-    if (!fuse_prep) {
+    if (!fuse_prep && (g_x_phase & 1)) {
         hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, c.x, B, D, c.meta, xq, inv, margin);
         QSAE_LAUNCH_CHECK();
     }
@@ -1156,7 +1246,7 @@ static int prefilter_submit(const PrefCall& c) {
                                 margin, kCandCap);
     if (rc != QSAE_OK) return rc;
     // 4. fp16 sweep of the remaining hidden units with the threshold filter (tau~ - 2 eps)
-    {
+    if (g_x_phase & 1) {
         using EpiS = EpiFilter<256, 128, 4, 2, true>;
         typename EpiS::Args es{c.bias ? c.bias + P : nullptr, tau, cand, cnt, kCandCap, P, fused_fill, c.dense_ld, inv, margin};
         if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
@@ -1194,10 +1284,21 @@ static int prefilter_submit(const PrefCall& c) {
         if (xstat && g_xstat_ablate != 0) return QSAE_OK;    // timing experiment: the lists are not trustworthy
     }
     // 5. survivors -> exact chain -> exact top-k (-> the row's reconstruction)
-    {
+    if (g_x_phase & 2) {
         const size_t lds = ref_lds_per_wave(D) * kRefWaves;
-        QSAE_SET_MAX_LDS_ONCE(refine_topk_kernel, 160 * 1024);
-        hipLaunchKernelGGL(refine_topk_kernel, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
+        // counted-wait form of the chains: at least kRefSets blocks of 32 per row, W addressable with 32-bit offsets
+        const bool counted = D / 32 >= kRefSets && static_cast<uint64_t>(H) * D * 4 < (1ull << 32);
+        auto kern = counted ? refine_topk_kernel<true> : refine_topk_kernel<false>;
+#ifdef QSAE_DEBUG_BUILD
+        if (counted && g_ref_ablate == 3) kern = refine_topk_kernel<true, 3>;
+        if (counted && g_ref_ablate == 4) kern = refine_topk_kernel<true, 4>;
+        if (counted && g_ref_ablate == 5) kern = refine_topk_kernel<true, 5>;
+        if (counted && g_ref_ablate == 6) kern = refine_topk_kernel<true, 6>;
+        if (g_ref_ablate >= 3) QSAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
+        QSAE_SET_MAX_LDS_ONCE(refine_topk_kernel<true>, 160 * 1024);
+        QSAE_SET_MAX_LDS_ONCE(refine_topk_kernel<false>, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
                            cnt, kCandCap, tau, margin, c.x, c.W, c.bias, B, D, H, k, c.idx, c.val, flags, g_ref_ablate, g_ref_stamps,
                            pl.filled, c.dense_ld, parts, cnt_parts,
                            c.dec ? *c.dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr});
@@ -1576,6 +1677,12 @@ extern "C" int qsae_debug_set_prefilter_tile(int which) {
     return QSAE_OK;
 }
 
+extern "C" int qsae_debug_set_phases(int phase_mask, int parts) {
+    g_x_phase = phase_mask;
+    g_x_parts = parts;
+    return QSAE_OK;
+}
+
 extern "C" int qsae_debug_set_sweep_kernel(int which) {
     g_sweep_kernel = which;
     return QSAE_OK;
@@ -1675,6 +1782,10 @@ extern "C" int qsae_prefilter_pack_w(const float* W, const float* bias, int H, i
     const long long n = static_cast<long long>(H) * D;
     hipLaunchKernelGGL(pref_w_cast_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, W, n, meta,
                        static_cast<_Float16*>(Wq));
+    QSAE_LAUNCH_CHECK();
+    // meta[3] has served (max |W| -> sw); from here on it holds the largest distance between a row and its fp16 copy
+    QSAE_HIP(hipMemsetAsync(meta + 3, 0, sizeof(float), s));
+    hipLaunchKernelGGL(pref_w_err_kernel, dim3((H + 3) / 4), dim3(256), 0, s, W, H, D, meta, reinterpret_cast<unsigned*>(meta + 3));
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }

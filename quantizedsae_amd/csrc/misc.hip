@@ -297,3 +297,27 @@ extern "C" int qsae_sq_err_sum(const float* recon, const float* x, size_t n, dou
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }
+
+#ifdef QSAE_DEBUG_BUILD
+// experiment support (debug library only): which XCD / CU a stream's workgroups land on -- out[2 i] = XCC_ID register,
+// out[2 i + 1] = HW_ID register of workgroup i; every workgroup spins ~20 us so that the grid spreads over the CUs
+namespace qsae {
+__global__ void cu_probe_kernel(unsigned* out) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 2000ull) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = xcc;
+        out[2 * blockIdx.x + 1] = hw;
+    }
+}
+}  // namespace qsae
+extern "C" int qsae_debug_cu_probe(unsigned* out, int workgroups, qsae_stream_t stream) {
+    using namespace qsae;
+    hipLaunchKernelGGL(cu_probe_kernel, dim3(workgroups), dim3(1024), 0, as_stream(stream), out);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+#endif

@@ -121,7 +121,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
             ss = lane_half ? so + ss : ss + so;              // same operand order in both lanes: identical sums
         }
         float sx;
-        pref_row_params(mx, ss, D, a.meta[0], a.meta[1], a.meta[2], sx, inv, margin_row);
+        pref_row_params(mx, ss, -1.0f, D, a.meta[0], a.meta[1], a.meta[2], a.meta[3], sx, inv, margin_row);   // (row error not measured here: worst case)
         if (blockIdx.y == 0 && row_ok && lane_half == 0) {
             a.inv_out[row] = inv;
             a.margin_out[row] = margin_row;

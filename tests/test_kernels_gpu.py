@@ -570,8 +570,9 @@ def test_prefilter_ordered_checkpoint_keeps_the_fast_path(fused_path):
 
 
 def test_prefilter_error_bound_holds_with_margin(fused_path):
-    """max |approx - exact chain| over the pilot block stays far below the eps_b the selection relies on
-    (inputs with outliers, tiny and huge scales)."""
+    """max |approx - exact chain| over the pilot block stays below the eps_b the selection relies on (inputs with
+    outliers, tiny and huge scales).  eps_b is built from the MEASURED distances between the operands and their fp16
+    copies (Cauchy-Schwarz on them), so the headroom is the slack of that inequality: ~2x or more on hardware."""
     from quantizedsae_amd import _lib
     ops = _ops()
     B, D, H, k = 600, 512, 8192, 65
@@ -602,7 +603,7 @@ def test_prefilter_error_bound_holds_with_margin(fused_path):
     exact = oracle.encode(x, W[:P], bias[:P])
     ratio = np.abs(approx.astype(np.float64) - exact).max(axis=1) / (margin / 2.0)
     assert np.isfinite(ratio).all()
-    assert ratio.max() < 0.25, ratio.max()                 # >= 4x headroom on hardware
+    assert ratio.max() < 0.6, ratio.max()                  # the bound itself is ratio <= 1
 
 
 def test_prefilter_degenerate_rows_fall_back(fused_path):
