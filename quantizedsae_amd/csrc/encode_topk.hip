@@ -909,7 +909,8 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         for (int i = 0; i < 8; ++i) {
             int jj = j0 + 8 * i + (lane >> 3);
             jj = jj < m ? jj : j0;
-            const int row = ablate == 1 ? (lane >> 3) : hidx[jj];
+            // (timing experiments: 1 = eight fixed rows, L1 hits; 7 = every XCD gathers from 1024 rows of its own, L2 hits)
+            const int row = ablate == 1 ? (lane >> 3) : ablate == 7 ? ((hidx[jj] & 1023) | ((blockIdx.x & 7) << 10)) : hidx[jj];
             if (kCounted) voff[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
             else voff[i] = static_cast<int64_t>(row) * (D * 4) + 16 * (lane & 7);
         }

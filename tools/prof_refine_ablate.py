@@ -47,10 +47,11 @@ torch.cuda.synchronize()
 del h
 lib.qsae_debug_set_phases(2, 0)
 names = {0: "complete", 1: "gathers from 8 fixed rows (L1 hits)", 3: "no scalar loads of x", 4: "no LDS transpose",
-         5: "no gathers in the main loop", 6: "no scalar loads, no LDS transpose"}
+         5: "no gathers in the main loop", 6: "no scalar loads, no LDS transpose",
+         7: "every XCD gathers from 1024 rows of its own (2 MiB: L2 hits)"}
 # (ablation 2, "no chains", leaves the keys uninitialised: the ranked indices are garbage and the dense / decode writes
 # that follow fault -- never run it with outputs attached)
-for abl in (0, 1, 3, 4, 5, 6, 0):
+for abl in (0, 1, 3, 4, 5, 6, 7, 0):
     lib.qsae_debug_set_refine_ablate(abl)
     print(f"refinement + decode, ablation {abl} ({names[abl]}): {timed(submit):.3f} ms", flush=True)
 lib.qsae_debug_set_refine_ablate(0)
