@@ -160,7 +160,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
     }
     char* bias_lds = xs_smem + BIAS_BASE;
     char* my_ring = xs_smem + RING_BASE + wave * RING_WAVE + lane * 4;     // this lane's slot 0
-    if (!a.bias && tid < 3 * kXsHT) reinterpret_cast<float*>(bias_lds)[tid] = 0.f;   // no bias: the copies stay zero
+    // no bias: the three copies stay zero.  With a bias, copies 1 and 2 start as zeros too (copy 0 arrives with the first
+    // block): the first sweep iteration filters a row tile of -inf against the copy "of the iteration before", which
+    // has to hold finite numbers even when no iteration has written it yet.
+    if (tid < 3 * kXsHT && (!a.bias || tid >= kXsHT)) reinterpret_cast<float*>(bias_lds)[tid] = 0.f;
     // Small batches have fewer 256-row panels than the chip has CUs: the hidden range is then split over
     // gridDim.y parts, each with its own segment of every row's candidate list and its own counter.
     const int part = blockIdx.y;
@@ -182,33 +185,45 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // One 1-KiB piece of iteration `ld` per call (i is a compile-time constant at every call site); wave 0 adds the
     // block's bias (kXsHT floats, lanes 0..kXsHT/4-1, 16 bytes each) to piece 0.  Three bias copies in rotation:
     // while iteration it+1 lands, the filter still reads copy it and copy it-1.
+    // Where iteration `ld` comes from and goes to: computed once per iteration (next_block), in SGPRs -- worked out per
+    // piece (a compare and two branches for block_of, 64-bit address arithmetic) it cost a dozen scalar instructions
+    // and three branches in front of every one of the eight DMA issues of a stage.  Past the last iteration the last
+    // block is fetched once more (into the buffer nobody reads any more): no branch around the issues either.
+    const char* nx_src = nullptr;                            // block base, opaque scalar pair: SGPR base + 32-bit lane offset
+    const char* nx_bias = nullptr;                           // addressing (otherwise the compiler hoists `wq + voff[i]`
+    char* nx_dst = nullptr;                                  // as eight 64-bit VGPR pairs out of the loops and spills them)
+    char* nx_bias_dst = nullptr;
+    auto scalar_ptr = [](const void* p) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u));
+        const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
+        return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+    };
+    auto next_block = [&]() {
+        const int blk = block_of(ld < n_iter ? ld : n_iter - 1);
+        nx_src = scalar_ptr(reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(blk) * STAGE_BYTES);
+        nx_dst = xs_smem + (ld % kXsStages) * STAGE_BYTES;
+        if (a.bias) {
+            nx_bias = scalar_ptr(a.bias + static_cast<int64_t>(blk) * kXsHT);
+            nx_bias_dst = bias_lds + (ld % 3) * BIAS_BYTES;
+        }
+    };
     auto issue_piece = [&](int i) {
-        const int blk = block_of(ld);
-        char* dst = xs_smem + (ld % kXsStages) * STAGE_BYTES;
-        // block base as an opaque scalar pair: SGPR base + 32-bit lane offset addressing (otherwise the compiler
-        // hoists `wq + voff[i]` as eight 64-bit VGPR pairs out of the loops and spills them)
-        auto scalar_ptr = [](const void* p) {
-            const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-            const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u));
-            const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
-            return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
-        };
-        const char* sb = scalar_ptr(reinterpret_cast<const char*>(a.wq) + static_cast<int64_t>(blk) * STAGE_BYTES);
         unsigned vo = voff[i];
         asm volatile("" : "+v"(vo));                        // keep the offsets 32-bit (no hoisted zero-extended pairs)
-        __builtin_amdgcn_global_load_lds((gptr_t)(sb + vo), (lptr_t)(dst + piece[i] * 1024), 16, 0, 0);
-        if (i == 0 && a.bias && wave == 0 && lane < kXsHT / 4) {
-            const char* bb = scalar_ptr(a.bias + static_cast<int64_t>(blk) * kXsHT);
-            __builtin_amdgcn_global_load_lds((gptr_t)(bb + static_cast<unsigned>(16 * lane)),
-                                             (lptr_t)(bias_lds + (ld % 3) * BIAS_BYTES), 16, 0, 0);
-        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(nx_src + vo), (lptr_t)(nx_dst + piece[i] * 1024), 16, 0, 0);
+        if (i == 0 && a.bias && wave == 0 && lane < kXsHT / 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(nx_bias + static_cast<unsigned>(16 * lane)), (lptr_t)nx_bias_dst, 16, 0, 0);
     };
     auto issue = [&]() {
 #pragma unroll
         for (int i = 0; i < IPW; ++i) issue_piece(i);
         ++ld;
     };
-    if (ld < n_iter) issue();
+    if (n_iter > 0) {
+        next_block();
+        issue();
+    }
     // Make the compiler retire its own loads (x fragments, threshold, scale) HERE: it cannot see the asm
     // waits below, and a load still pending in its model at the loop header costs a vmcnt(0) per stage.
     float thr_r = thr, inv_r = inv;
@@ -467,7 +482,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
 #pragma unroll
             for (int u = 0; u < VPG; ++u) epilogue((kb / 2) * VPG + u);
             if (phase == 0) {
-                if (dma && kb / 4 < IPW) issue_piece(kb / 4);
+                if (dma && kb / 4 < IPW) issue_piece(kb / 4);   // (dma is a compile-time constant at every call site)
             } else {
                 fill_one();
                 fill_one();
@@ -505,17 +520,18 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // of the previous tile 1), (fill stores + MFMAs of row tile 1 + epilogue of tile 0), counted wait, barrier.
     // Written once, instantiated for the pilot loop and the sweep loop (two loops, so that the pilot's maxima
     // do not occupy registers during the sweep).
-    auto iteration = [&](int it, bool first) __attribute__((always_inline)) {
+    auto iteration = [&](int it) __attribute__((always_inline)) {
         // records in the slots: row tile 0 of the previous iteration's block, row tile 1 of the one before it
         flush(block_of(it > 0 ? it - 1 : 0), block_of(it > 1 ? it - 2 : 0));   // older than the DMA issued next
         stamp(0);
-        const bool dma = ld < n_iter;                        // iteration it+1 -> the buffer read during it-1
+        next_block();                                        // iteration it+1 -> the buffer read during it-1
         fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
-        // first pass: epilogue of the previous iteration's row tile 1 (none at the first pilot / first sweep iteration)
-        tile_pass(sbase, 0, !first, 1, 0, it - 1, 0, dma);
-        if (dma) ++ld;
+        // first pass: epilogue of the previous iteration's row tile 1 (at the first sweep iteration acc[1] is -inf: nothing
+        // passes -- a run-time guard here was a scalar compare and a branch in front of every filtered value)
+        tile_pass(sbase, 0, true, 1, 0, it + 2, 0, true);       // (bias copy (it - 1) mod 3, written without a negative operand)
+        ++ld;
         // a lane that already holds five records could overflow its nine slots in the second pass: flush now (only
         // row tile 1 records of the previous block are there; rare; the stores are younger than the stage's DMA,
         // which only makes the wait below stricter)
@@ -535,13 +551,13 @@ sweep_xstat_f16_kernel(XsArgs a) {
         // not worth hiding; deferring them as the sweep does would keep 16 more registers live)
 #pragma unroll 1
         for (int it = 0; it < ps; ++it) {
-            const bool dma = ld < n_iter;
+            next_block();
             fill_begin_stage();
             const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                tile_pass(sbase, mt, false, 0, 0, 0, mt, mt == 0 && dma);
-                if (mt == 0 && dma) ++ld;
+                tile_pass(sbase, mt, false, 0, 0, 0, mt, mt == 0);
+                if (mt == 0) ++ld;
                 if (FILTER) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -560,8 +576,11 @@ sweep_xstat_f16_kernel(XsArgs a) {
         thr_r = tau_row - margin_row;
         if (part == 0 && row_ok && lane_half == 0) a.tau_out[row] = tau_row;
     }
+    // nothing of "the previous iteration's row tile 1" exists at the first sweep iteration
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][r] = -__builtin_huge_valf();
 #pragma unroll 1
-    for (int it = ps; it < n_iter; ++it) iteration(it, it == ps);
+    for (int it = ps; it < n_iter; ++it) iteration(it);
     while (FILL && a.dense && fill_next < fill_total) {              // (quota * iterations covers the block; safety net)
         fill_begin_stage();
         while (fill_left > 0) fill_one();
