@@ -41,7 +41,7 @@ constexpr int kCandCap = 1024;     // candidate slots per row
 constexpr int kFusedMinRows = 2048;
 constexpr int kFusedMinHidden = 8192;
 constexpr int kFillCoWaves = 1024; // fill waves beside the sweep: one per SIMD, so every sweep wave has the same neighbour
-constexpr int kFillCoPace = 4;     // s_sleep(1) per store: the fill ends with the sweep (measured scan in the kernel's comment)
+constexpr int kFillCoPace = 3;     // s_sleep(1) per store: the fill ends with the sweep (scan in the kernel's comment; 4 until the sweep lost 0.12 ms in round 2)
 
 // Tuning / ablation switches.  The product library (libqsae_hip.so) is built without QSAE_DEBUG_BUILD: every switch is
 // a compile-time constant there, no qsae_debug_* symbol exists and no ablation kernel is instantiated.  The debug
