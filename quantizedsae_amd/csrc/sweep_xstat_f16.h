@@ -520,9 +520,18 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // of the previous tile 1), (fill stores + MFMAs of row tile 1 + epilogue of tile 0), counted wait, barrier.
     // Written once, instantiated for the pilot loop and the sweep loop (two loops, so that the pilot's maxima
     // do not occupy registers during the sweep).
+    // The two waves of a SIMD (w and w + 4) flush at different points of a stage (no-fill build): a flush is ~600
+    // cycles of VALU, LDS and store issue without a single MFMA, and with both waves flushing right behind the barrier
+    // the matrix pipe of the SIMD idles for that long every stage.  Waves 0-3 flush at the top of the stage, waves 4-7
+    // between the two row-tile passes (their records: row tiles 0 and 1 of the previous iteration's block).  Same
+    // records, same lists (a row's list is written by one wave only, in the same order).
+    // (sweep + fill 2.41 -> 2.37 ms.  Only in the no-fill build: with the zero-fill inside the sweep the fill stores have to
+    // stay the youngest vector-memory operations of a stage.)
+    constexpr bool STAGGER = ABL == 9;
+    const bool late_wave = STAGGER && wave >= 4;             // wave-uniform
     auto iteration = [&](int it) __attribute__((always_inline)) {
         // records in the slots: row tile 0 of the previous iteration's block, row tile 1 of the one before it
-        flush(block_of(it > 0 ? it - 1 : 0), block_of(it > 1 ? it - 2 : 0));   // older than the DMA issued next
+        if (!late_wave) flush(block_of(it > 0 ? it - 1 : 0), block_of(it > 1 ? it - 2 : 0));   // older than the DMA issued next
         stamp(0);
         next_block();                                        // iteration it+1 -> the buffer read during it-1
         fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
@@ -535,13 +544,16 @@ sweep_xstat_f16_kernel(XsArgs a) {
         // a lane that already holds five records could overflow its nine slots in the second pass: flush now (only
         // row tile 1 records of the previous block are there; rare; the stores are younger than the stage's DMA,
         // which only makes the wait below stricter)
-        if (__builtin_amdgcn_ballot_w64(waddr > ring_addr + 4u * 256u) != 0ull) flush(0, block_of(it > 0 ? it - 1 : 0));
+        if (late_wave || __builtin_amdgcn_ballot_w64(waddr > ring_addr + 4u * 256u) != 0ull) {
+            const int prev = block_of(it > 0 ? it - 1 : 0);
+            flush(prev, prev);                               // (waves 0-3 hold no row tile 0 records at this point)
+        }
         stamp(2);
         tile_pass(sbase, 1, true, 0, 0, it, 1, false);
         stamp(3);
         while (fill_left > 0) fill_one();                    // (budgets beyond the 16 slots of a stage)
         // retire iteration it+1 (for every wave) before anyone reads it; also frees this iteration's buffer
-        wait_all_but(nfill);
+        wait_all_but(late_wave ? 0 : nfill);                  // (waves 4-7: their flush's stores are younger than the DMA)
         stamp(4);
         __builtin_amdgcn_s_barrier();
         stamp(5);
