@@ -373,7 +373,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const long long fill_step = fill_linear ? static_cast<long long>(kXsWaves - 1) * a.fill_cw : 0;
     // One piece per call, at most a.fill_cw per stage; the calls sit between the MFMA groups of the stage
     // (a burst of nine 1-KiB stores at the top of a stage overruns the write queues and stalls the wave).
-    constexpr bool FILL = ABL != 9;                          // ABL 9: no fill code at all (the zeros come from a co-resident fill kernel)
+    constexpr bool FILL = ABL != 9 && ABL != 10;             // ABL 9: no fill code at all (the zeros come from a co-resident fill kernel); 10 = 9 + stamps
     int fill_left = 0, nfill = 0;                            // budget / store instructions issued this stage
     int fill_r = 0, fill_c = 0;
     auto fill_begin_stage = [&]() {
@@ -431,13 +431,13 @@ sweep_xstat_f16_kernel(XsArgs a) {
     static_assert(MT == 2 && KB % 4 == 0, "the interleave below is written for two row tiles");
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int which) {
-        if (ABL >= 5) {
+        if (ABL >= 5 && ABL != 9) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             tacc[which] += t - tprev;
             tprev = t;
         }
     };
-    if (ABL >= 5) tprev = __builtin_amdgcn_s_memtime();
+    if (ABL >= 5 && ABL != 9) tprev = __builtin_amdgcn_s_memtime();
     constexpr bool FILTER = ABL != 2 && ABL != 8;
     constexpr int VPG = 32 / KB;                             // filter values per pair of MFMAs (KB = 32: 1)
     static_assert(VPG >= 1 && VPG * (KB / 2) == 16, "16 values spread over KB/2 MFMA pairs");
@@ -527,7 +527,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // records, same lists (a row's list is written by one wave only, in the same order).
     // (sweep + fill 2.41 -> 2.37 ms.  Only in the no-fill build: with the zero-fill inside the sweep the fill stores have to
     // stay the youngest vector-memory operations of a stage.)
-    constexpr bool STAGGER = ABL == 9;
+    constexpr bool STAGGER = ABL == 9 || ABL == 10;
     const bool late_wave = STAGGER && wave >= 4;             // wave-uniform
     auto iteration = [&](int it) __attribute__((always_inline)) {
         // records in the slots: row tile 0 of the previous iteration's block, row tile 1 of the one before it
@@ -597,8 +597,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
         fill_begin_stage();
         while (fill_left > 0) fill_one();
     }
-    if (ABL >= 5) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }
-    if (ABL >= 5 && a.stamps && lane == 0) {
+    if (ABL >= 5 && ABL != 9) { asm volatile("" : "+v"(acc[0]), "+v"(acc[1])); }
+    if (ABL >= 5 && ABL != 9 && a.stamps && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.stamps[(static_cast<size_t>(blockIdx.x) * kXsWaves + wave) * 8 + i] = tacc[i];
     }
@@ -651,6 +651,7 @@ inline int launch_xstat(int D, const XsArgs& a, hipStream_t stream, int ablate =
     if (D == 512 && ablate == 6) return launch_xstat_one<32, 6>(a, stream);
     if (D == 512 && ablate == 7) return launch_xstat_one<32, 7>(a, stream);
     if (D == 512 && ablate == 8) return launch_xstat_one<32, 8>(a, stream);
+    if (D == 512 && ablate == 10) return launch_xstat_one<32, 10>(a, stream);
 #endif
     if (D == 512 && ablate == 9) return launch_xstat_one<32, 9>(a, stream);
     switch (D) {

@@ -22,7 +22,7 @@ stamps = torch.zeros((B // 256, 8, 8), dtype=torch.int64, device="cuda:0")
 lib.qsae_debug_set_xstat_stamps(C.c_void_p(stamps.data_ptr()))
 names = ["flush", "fill setup", "pass 0 (tile 0 MFMAs + DMA issue + filter of previous tile 1)", "pass 1 (tile 1 MFMAs + fill + filter of tile 0)", "vmcnt wait", "barrier"]
 nst = H // 64          # iterations of the stamped sweep loop (the in-kernel pilot's 32 iterations are not stamped)
-for label, tile in (("full kernel", 15), ("no hits", 17), ("no filter", 18)):
+for label, tile in (("full kernel", 15), ("no hits", 17), ("no filter", 18), ("product form: no fill code, staggered flush", 20)):
     lib.qsae_debug_set_prefilter_tile(tile)
     for _ in range(3):
         try:
