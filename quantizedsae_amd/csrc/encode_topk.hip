@@ -1257,7 +1257,8 @@ static int prefilter_submit(const PrefCall& c) {
                       fill_cw, inkernel ? P / kXsHT : 0, g_inkernel_rank > 0 ? g_inkernel_rank : inkernel_rank(k), tau,
                       fuse_prep ? c.x : nullptr, c.meta, inv, margin, parts, cnt_parts};
             if (fill_co) QSAE_HIP(hipEventRecord(ctx->ev_fork, s));     // everything before the sweep (x prep, earlier users of `dense`)
-            rc = launch_xstat(D, xa, s, fill_co ? 9 : g_xstat_ablate);
+            // (the build without fill code whenever this launch has no zeros to write itself)
+            rc = launch_xstat(D, xa, s, (g_xstat_ablate == 0 && D == 512 && !fill_in_sweep) ? 9 : g_xstat_ablate);
             if (fill_co && rc == QSAE_OK) {
                 // The zeros are written by a second kernel beside the sweep, on this thread's side stream for this
                 // device: forked from `s` at ev_fork, joined back at ev_join (both events belong to this thread, and a
@@ -1582,7 +1583,7 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
     if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
     XsArgs xa{xq, Wq, bias, tau, margin, inv, cand, cnt, B, H, kBitsCap, 0, g_xstat_rot, nullptr, nullptr, 0, H, 0, 0, 0,
               nullptr, nullptr, meta, nullptr, nullptr, parts, cnt_parts};
-    int rc = launch_xstat(D, xa, s, 0);
+    int rc = launch_xstat(D, xa, s, D == 512 ? 9 : 0);      // (nothing to zero-fill here: the build without fill code)
     if (prof.end) QSAE_HIP(hipEventRecord(prof.end, s));
     if (rc != QSAE_OK) return rc;
     {

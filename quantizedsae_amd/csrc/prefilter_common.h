@@ -48,6 +48,7 @@ __device__ __forceinline__ void pref_row_params(float mx, float ss, float ee, in
         eps = en * wn + (nrm + en) * fn                             // fp16 copies of x and W (see above)
               + 5.0f * D * u * nrm * wn                             // 4x fp32 accumulation in the matrix core + the exact chain's roundings
               + (D + 8.0f) * u * bmax                               // every chain step (and the final fma) also rounds at the bias' magnitude
+              + 4.0f * D * u * bmax                                 // ... and so does the approximate chain, which starts from the bias
               + 8.0f * u * nrm * wn
               + 4.0e-6f * (nrm * wn + bmax);                        // candidate records carry the latent truncated by < 2^-18
         eps *= 1.0001f;

@@ -141,7 +141,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
     }
     const float thr = a.pilot_stages > 0 ? 0.0f : a.tau[crow] - margin_row;      // in-kernel pilot: set after the pilot pass
 
-    // ---- DMA addressing: instruction i of this wave covers chunks (wave*IPW + i)*64 .. +63 ---------
+    // ---- DMA addressing: a piece = 64 consecutive 16-byte chunks (1 KiB) of the stage ---------------------
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     // Workgroups of one XCD stream the same rows in lockstep; started on the same row they would all queue
@@ -149,15 +149,6 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // stage in its own rotation (pieces = 64-chunk groups; the LDS image is unchanged).
     constexpr int PIECES = kXsHT * CPR / 64;
     const int rot = ((blockIdx.x >> 3) * a.rot_mul) % PIECES;
-    unsigned voff[IPW];                                      // per-lane byte offsets inside a stage (constant)
-    int piece[IPW];
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-        piece[i] = (wave * IPW + i + rot) % PIECES;
-        const int c = piece[i] * 64 + lane;
-        const int r = c / CPR, pos = c % CPR;
-        voff[i] = static_cast<unsigned>((r * CPR + (pos ^ (r & SW))) * 16);
-    }
     char* bias_lds = xs_smem + BIAS_BASE;
     char* my_ring = xs_smem + RING_BASE + wave * RING_WAVE + lane * 4;     // this lane's slot 0
     // no bias: the three copies stay zero.  With a bias, copies 1 and 2 start as zeros too (copy 0 arrives with the first
@@ -208,18 +199,37 @@ sweep_xstat_f16_kernel(XsArgs a) {
             nx_bias_dst = bias_lds + (ld % 3) * BIAS_BYTES;
         }
     };
+    // Waves 0-3 issue all the DMA pieces of a stage (two per MFMA group of their first row-tile pass), waves 4-7 none:
+    // the younger wave of a SIMD (w + 4) loses the issue arbitration against its partner all stage long and is the one
+    // everybody waits for at the barrier (waves 0-3 idle ~1000 cycles there); the ~80 cycles an LDS-DMA issue costs are
+    // better spent by the wave that has them to spare (sweep + fill 2.40 -> 2.35 ms).  Lane offsets on the fly (an
+    // XOR and a shift-add per piece) instead of a register per piece.
+    // (No-fill builds only: with the fill inside the sweep the extra registers of two issues per group spill.)
+    constexpr bool DMAE = ABL == 9 || ABL == 10;
+    constexpr int IPD = DMAE ? 2 * IPW : IPW;                // pieces per issuing wave
+    const bool dma_wave = !DMAE || wave < kXsWaves / 2;      // wave-uniform
     auto issue_piece = [&](int i) {
-        unsigned vo = voff[i];
-        asm volatile("" : "+v"(vo));                        // keep the offsets 32-bit (no hoisted zero-extended pairs)
-        __builtin_amdgcn_global_load_lds((gptr_t)(nx_src + vo), (lptr_t)(nx_dst + piece[i] * 1024), 16, 0, 0);
+        if (!dma_wave) return;
+        const int pc = (wave * IPD + i + rot) % PIECES;      // scalar
+        unsigned vo;
+        if (CPR == 64) {                                      // one piece = one hidden row: row scalar, chunk = lane
+            vo = (static_cast<unsigned>(lane ^ (pc & SW)) << 4) + static_cast<unsigned>(pc * 1024);
+        } else {
+            const int c = pc * 64 + lane;
+            const int r = c / CPR, pos = c % CPR;
+            vo = static_cast<unsigned>((r * CPR + (pos ^ (r & SW))) * 16);
+        }
+        asm volatile("" : "+v"(vo));
+        __builtin_amdgcn_global_load_lds((gptr_t)(nx_src + vo), (lptr_t)(nx_dst + pc * 1024), 16, 0, 0);
         if (i == 0 && a.bias && wave == 0 && lane < kXsHT / 4)
             __builtin_amdgcn_global_load_lds((gptr_t)(nx_bias + static_cast<unsigned>(16 * lane)), (lptr_t)nx_bias_dst, 16, 0, 0);
     };
     auto issue = [&]() {
 #pragma unroll
-        for (int i = 0; i < IPW; ++i) issue_piece(i);
+        for (int i = 0; i < IPD; ++i) issue_piece(i);
         ++ld;
     };
+
     if (n_iter > 0) {
         next_block();
         issue();
@@ -228,6 +238,12 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // waits below, and a load still pending in its model at the loop header costs a vmcnt(0) per stage.
     float thr_r = thr, inv_r = inv;
     asm volatile("" : "+v"(thr_r), "+v"(inv_r));
+    // The sweep compares in the accumulator's own scale: the MFMA chain of a row tile starts from bias * rinv instead of
+    // zero (rinv = s_x s_w, a power of two: exact), so an accumulator IS (latent * rinv) and the filter needs no v_fma
+    // per value -- it compares with thr * rinv, and a record is scaled back by inv (exact) when it is flushed.  The
+    // roundings of the chain now happen at the bias' magnitude, too: eps_b has a term for that (prefilter_common.h).
+    const float rinv_r = inv_r > 0.f ? 1.0f / inv_r : 0.f;   // (inv = 0: row not servable, flagged whatever it lists)
+    float thr_s = thr_r * rinv_r;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(xf[kb]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -295,7 +311,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
                 if (j < mine && pos + j < cap_part) {
                     const unsigned q = rec & 15u;
                     const int h = ((rec & 16u) ? hb1 : hb0) + static_cast<int>(8u * (q >> 2) + (q & 3u));
-                    list[pos + j] = make_uint2(rec & 0xFFFFFFE0u, static_cast<unsigned>(h));
+                    list[pos + j] = make_uint2(__float_as_uint(__uint_as_float(rec & 0xFFFFFFE0u) * inv_r), static_cast<unsigned>(h));
                 }
             };
             // slot j holds a record only for lanes with more than j of them: stop at the first empty level
@@ -332,10 +348,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // One value of the filter: accumulator register q of row tile mt (bias quad bq = rows 8g..8g+3 [+4 for the upper
     // half-wave] of that tile, g = q / 4).  EXEC <- !(v < thr) (at or above the threshold, or NaN); the hit lanes write
     // their record and advance their write position; EXEC <- all.  After every fourth value the position is clamped.
-    auto filter_value = [&](int mt, int q, const f32x4& bq) {
-        const float v = fmaf(acc[mt][q], inv_r, bq[q & 3]);
+    auto filter_value = [&](int mt, int q) {
+        const float v = acc[mt][q];                          // latent * rinv (the chain started from bias * rinv)
         const unsigned rec = (__float_as_uint(v) & 0xFFFFFFE0u) | static_cast<unsigned>(mt * 16 + q);
-        const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_r;
+        const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_s;
         asm volatile("v_cmpx_nlt_f32_e32 vcc, %[v], %[thr]\n\t"
                      "ds_write_b32 %[addr], %[rec]\n\t"
                      "v_add_u32_e32 %[addr], 0x100, %[addr]\n\t"
@@ -457,22 +473,33 @@ sweep_xstat_f16_kernel(XsArgs a) {
         const float v = fmaf(acc[mt][q], inv_r, bq[q & 3]);
         gmax[q] = fmaxf(gmax[q], v);                         // v_max_f32: a NaN operand is ignored
     };
-    // with_filter: in the MFMA shadows, filter acc[fmt] (block fblk, bias copy of iteration fit)
-    auto tile_pass = [&](const char* sbase, int mt, bool with_filter, int fmt, int fblk, int fit, int phase,
+    // with_filter: in the MFMA shadows, filter acc[fmt].  cit >= 0: the chain of row tile mt starts from the bias of
+    // iteration cit's block (copy cit % 3) times rinv -- the sweep; cit < 0: from zero -- the pilot pass.
+    auto tile_pass = [&](const char* sbase, int mt, bool with_filter, int fmt, int cit, int phase,
                          bool dma) __attribute__((always_inline)) {
         // MFMAs of row tile mt over all of K; in their shadows the epilogue of acc[fmt]
         auto rd = [&](int kb) {
             return *reinterpret_cast<const f16x8*>(sbase + off[kb & 7] + 256 * (kb >> 3) + mt * (32 * CPR * 16));
         };
-        f32x4 bq[4];
-        if (FILTER && with_filter) load_bias(fit, fmt, bq);
         auto epilogue = [&](int qv) {
-            if (FILTER && with_filter) filter_value(fmt, qv, bq[qv >> 2]);
+            if (FILTER && with_filter) filter_value(fmt, qv);
         };
         f16x8 w0 = rd(0), w1 = rd(1), w2, w3;
         f32x16 c;
+        if (cit >= 0) {
+            f32x4 bqc[4];
+            load_bias(cit, mt, bqc);
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 r2 = {rinv_r, rinv_r};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            for (int g = 0; g < 4; ++g) {                    // (two packed multiplies per accumulator quad)
+                const f32x2 lo = f32x2{bqc[g][0], bqc[g][1]} * r2, hi = f32x2{bqc[g][2], bqc[g][3]} * r2;
+                c[4 * g + 0] = lo[0]; c[4 * g + 1] = lo[1]; c[4 * g + 2] = hi[0]; c[4 * g + 3] = hi[1];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        }
 #pragma unroll
         for (int kb = 0; kb < KB; kb += 4) {
             w2 = rd(kb + 2); w3 = rd(kb + 3);
@@ -482,7 +509,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
 #pragma unroll
             for (int u = 0; u < VPG; ++u) epilogue((kb / 2) * VPG + u);
             if (phase == 0) {
-                if (dma && kb / 4 < IPW) issue_piece(kb / 4);   // (dma is a compile-time constant at every call site)
+                if (dma && kb / 4 < IPW) {                     // (dma: a compile-time constant at every call site)
+                    if (DMAE) { issue_piece(2 * (kb / 4)); issue_piece(2 * (kb / 4) + 1); }
+                    else issue_piece(kb / 4);
+                }
             } else {
                 fill_one();
                 fill_one();
@@ -539,7 +569,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
         const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
         // first pass: epilogue of the previous iteration's row tile 1 (at the first sweep iteration acc[1] is -inf: nothing
         // passes -- a run-time guard here was a scalar compare and a branch in front of every filtered value)
-        tile_pass(sbase, 0, true, 1, 0, it + 2, 0, true);       // (bias copy (it - 1) mod 3, written without a negative operand)
+        tile_pass(sbase, 0, true, 1, it, 0, true);
         ++ld;
         // a lane that already holds five records could overflow its nine slots in the second pass: flush now (only
         // row tile 1 records of the previous block are there; rare; the stores are younger than the stage's DMA,
@@ -549,7 +579,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
             flush(prev, prev);                               // (waves 0-3 hold no row tile 0 records at this point)
         }
         stamp(2);
-        tile_pass(sbase, 1, true, 0, 0, it, 1, false);
+        tile_pass(sbase, 1, true, 0, it, 1, false);
         stamp(3);
         while (fill_left > 0) fill_one();                    // (budgets beyond the 16 slots of a stage)
         // retire iteration it+1 (for every wave) before anyone reads it; also frees this iteration's buffer
@@ -568,7 +598,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
             const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                tile_pass(sbase, mt, false, 0, 0, 0, mt, mt == 0);
+                tile_pass(sbase, mt, false, 0, -1, mt, mt == 0);
                 if (mt == 0) ++ld;
                 if (FILTER) {
 #pragma unroll
@@ -586,6 +616,7 @@ sweep_xstat_f16_kernel(XsArgs a) {
         }
         const float tau_row = select_tau();
         thr_r = tau_row - margin_row;
+        thr_s = thr_r * rinv_r;
         if (part == 0 && row_ok && lane_half == 0) a.tau_out[row] = tau_row;
     }
     // nothing of "the previous iteration's row tile 1" exists at the first sweep iteration
@@ -605,10 +636,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
     if (FILTER && n_iter > ps) {
         // what the last iteration left (tile 0 of the last block, tile 1 of the one before), then the last block's tile 1
         flush(block_of(n_iter - 1), block_of(n_iter > 1 ? n_iter - 2 : 0));
-        f32x4 bq[4];
-        load_bias(n_iter - 1, 1, bq);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) filter_value(1, q, bq[q >> 2]);
+        for (int q = 0; q < 16; ++q) filter_value(1, q);
     }
     flush(0, block_of(n_iter - 1));
     if (row_ok && lane_half == 0) my_cnt[row] = count;
