@@ -657,33 +657,67 @@ pref_w_err_kernel(const float* __restrict__ W, int H, int D, const float* __rest
     if (lane == 0) atomicMax(out, __float_as_uint(sqrtf(ff) * 1.0001f));
 }
 
-// one wave per activation row: fp16 copy scaled by a per-row power of two, 1/(sx*sw), margin = 2*eps_b
+// one wave per activation row: fp16 copy scaled by a per-row power of two, 1/(sx*sw), margin = 2*eps_b.
+// NV > 0: D = 256 NV, the row stays in registers between the two passes (NV 16-byte loads per lane, read once);
+// NV = 0: any D, second pass from L1 / L2.
+template <int NV>
 __global__ void __launch_bounds__(256)
 pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ meta,
                    _Float16* __restrict__ xq, float* __restrict__ inv, float* __restrict__ margin) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B) return;
     const float* xr = x + static_cast<int64_t>(row) * D;
+    _Float16* qr = xq + static_cast<int64_t>(row) * D;
     float mx = 0.f, ss = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float v = xr[d];
-        const float a = fabsf(v);
-        mx = (a > mx || a != a) ? a : mx;
-        ss = fmaf(v, v, ss);
+    f32x4 keep[NV > 0 ? NV : 1];
+    if (NV > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) keep[j] = *reinterpret_cast<const f32x4*>(xr + 256 * j + 4 * lane);
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = keep[j][e], a = fabsf(v);
+                mx = (a > mx || a != a) ? a : mx;
+                ss = fmaf(v, v, ss);
+            }
+    } else {
+        for (int d = lane; d < D; d += 64) {
+            const float v = xr[d];
+            const float a = fabsf(v);
+            mx = (a > mx || a != a) ? a : mx;
+            ss = fmaf(v, v, ss);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_xor(mx, off, 64);
         mx = (o > mx || o != o) ? o : mx;
         ss += __shfl_xor(ss, off, 64);
     }
-    // second pass over the row (L1 / L2 hits): the fp16 copy and its distance from the row
+    // the fp16 copy and its distance from the row
     const float sx0 = pow2_scale_for(mx), back = sx0 > 0.f ? 1.0f / sx0 : 0.f;
     float ee = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        const float v = xr[d];
-        xq[static_cast<int64_t>(row) * D + d] = static_cast<_Float16>(v * sx0);
-        const float e = fp16_input_error(v, v * sx0, back);
-        ee = fmaf(e, e, ee);
+    if (NV > 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = keep[j][e];
+                q[e] = static_cast<_Float16>(v * sx0);
+                const float er = fp16_input_error(v, v * sx0, back);
+                ee = fmaf(er, er, ee);
+            }
+            *reinterpret_cast<f16x4*>(qr + 256 * j + 4 * lane) = q;
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) {
+            const float v = xr[d];
+            qr[d] = static_cast<_Float16>(v * sx0);
+            const float e = fp16_input_error(v, v * sx0, back);
+            ee = fmaf(e, e, ee);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) ee += __shfl_xor(ee, off, 64);
     float sx, iv, mg;
@@ -692,6 +726,15 @@ pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __res
         inv[row] = iv;
         margin[row] = mg;
     }
+}
+
+static void launch_x_prep(const float* x, int B, int D, const float* meta, _Float16* xq, float* inv, float* margin, hipStream_t s) {
+    const dim3 grid((B + 3) / 4), block(256);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(xq) % 8 == 0);
+    if (vec && D == 512) hipLaunchKernelGGL(pref_x_prep_kernel<2>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
+    else if (vec && D == 256) hipLaunchKernelGGL(pref_x_prep_kernel<1>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
+    else if (vec && D == 1024) hipLaunchKernelGGL(pref_x_prep_kernel<4>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
+    else hipLaunchKernelGGL(pref_x_prep_kernel<0>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
 }
 
 // pilot epilogue: approximate dense latents of the first P hidden units, rows = activations (registers),
@@ -1221,7 +1264,7 @@ static int prefilter_submit(const PrefCall& c) {
     //    this in its own prologue, straight into registers)
     const bool fuse_prep = inkernel && g_fuse_xprep;
     if (!fuse_prep && (g_x_phase & 1)) {
-        hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, c.x, B, D, c.meta, xq, inv, margin);
+        launch_x_prep(c.x, B, D, c.meta, xq, inv, margin, s);
         QSAE_LAUNCH_CHECK();
     }
     const int Kw = D / 2;                                    // 4-byte words per fp16 row
@@ -1577,7 +1620,7 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
     QSAE_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tau), static_cast<int>(QSAE_SIG_GT_BITS), B, s));
     if (words_ld > words)
         QSAE_HIP(hipMemset2DAsync(zbits + words, words_ld * 4, 0, (words_ld - words) * 4, B, s));
-    hipLaunchKernelGGL(pref_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta, xq, inv, margin);
+    launch_x_prep(x, B, D, meta, xq, inv, margin, s);
     QSAE_LAUNCH_CHECK();
     const int parts = xstat_parts(B, H, kBitsCap);
     if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
