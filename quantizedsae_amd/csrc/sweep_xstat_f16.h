@@ -561,9 +561,12 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const bool late_wave = STAGGER && wave >= 4;             // wave-uniform
     auto iteration = [&](int it) __attribute__((always_inline)) {
         // records in the slots: row tile 0 of the previous iteration's block, row tile 1 of the one before it
-        if (!late_wave) flush(block_of(it > 0 ? it - 1 : 0), block_of(it > 1 ? it - 2 : 0));   // older than the DMA issued next
+        // (sweep iterations work on consecutive blocks: plain arithmetic, no block_of with its compare and branch; the
+        // first two iterations have no such records yet and do not use the numbers)
+        const int cur = s_begin + (it - ps);
+        if (!late_wave) flush(cur - 1, cur - 2);             // older than the DMA issued next
         stamp(0);
-        next_block();                                        // iteration it+1 -> the buffer read during it-1
+        if (dma_wave) next_block();                          // iteration it+1 -> the buffer read during it-1
         fill_begin_stage();                                  // fill stores: the youngest vector-memory operations of the stage
         stamp(1);
         const char* sbase = xs_smem + (it % kXsStages) * STAGE_BYTES;
@@ -574,10 +577,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
         // a lane that already holds five records could overflow its nine slots in the second pass: flush now (only
         // row tile 1 records of the previous block are there; rare; the stores are younger than the stage's DMA,
         // which only makes the wait below stricter)
-        if (late_wave || __builtin_amdgcn_ballot_w64(waddr > ring_addr + 4u * 256u) != 0ull) {
-            const int prev = block_of(it > 0 ? it - 1 : 0);
-            flush(prev, prev);                               // (waves 0-3 hold no row tile 0 records at this point)
-        }
+        if (late_wave || __builtin_amdgcn_ballot_w64(waddr > ring_addr + 4u * 256u) != 0ull)
+            flush(cur - 1, cur - 1);                         // (waves 0-3 hold no row tile 0 records at this point)
         stamp(2);
         tile_pass(sbase, 1, true, 0, it, 1, false);
         stamp(3);
