@@ -50,7 +50,7 @@ __device__ __forceinline__ void pref_row_params(float mx, float ss, float ee, in
               + (D + 8.0f) * u * bmax                               // every chain step (and the final fma) also rounds at the bias' magnitude
               + 4.0f * D * u * bmax                                 // ... and so does the approximate chain, which starts from the bias
               + 8.0f * u * nrm * wn
-              + 4.0e-6f * (nrm * wn + bmax);                        // candidate records carry the latent truncated by < 2^-18
+              + 8.0e-6f * (nrm * wn + bmax);                        // candidate records carry the latent truncated by < 2^-17
         eps *= 1.0001f;
         inv = (1.0f / sx) * (1.0f / sw);                            // powers of two: exact
     }

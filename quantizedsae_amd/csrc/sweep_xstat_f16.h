@@ -281,9 +281,10 @@ sweep_xstat_f16_kernel(XsArgs a) {
     const unsigned ring_limit = ring_addr + kXsClamp * 256u;
     unsigned waddr = ring_addr;                              // next free record slot of this lane
     const int lane_h = a.hidden_offset + 4 * lane_half;
-    // Records are 4 bytes: the approximate latent with its low 5 mantissa bits replaced by (row tile << 4 | accumulator
-    // register), i.e. which of the lane's 32 values of a block it is; the block itself is known at flush time (tile 0
-    // records belong to block blk0, tile 1 records to blk1).  The truncation (< 2^-18 relative, towards zero) is part
+    // Records are 4 bytes: the approximate latent (in the accumulator's scale) with its low 6 mantissa bits replaced by
+    // the value's place inside its 64-unit block (32 x row tile + 8 x accumulator quad + register in the quad; the
+    // half-wave's + 4 comes from the lane); the block itself is known at flush time (tile 0 records belong to block
+    // blk0, tile 1 records to blk1).  The truncation (< 2^-17 relative, towards zero) is part
     // of the error budget (prefilter_common.h).
     auto flush = [&](int blk0, int blk1) {
         if (__builtin_amdgcn_ballot_w64(waddr != ring_addr) != 0ull) {
@@ -306,12 +307,16 @@ sweep_xstat_f16_kernel(XsArgs a) {
                          : "=&v"(rr[0]), "=&v"(rr[1]), "=&v"(rr[2]), "=&v"(rr[3])
                          : "v"(ring_addr)
                          : "memory");
-            const int hb0 = blk0 * kXsHT + lane_h, hb1 = blk1 * kXsHT + 32 + lane_h;
+            // a record's low six bits are the value's place inside its 64-unit block (see filter_value): hidden index =
+            // block base + place; one limit for "mine" and "room in the list", one pointer for the lane's run of entries
+            const int hb0 = blk0 * kXsHT + lane_h, hb1 = blk1 * kXsHT + lane_h;
+            const int room = cap_part - pos;
+            const int lim = mine < room ? mine : room;
+            uint2* wp = list + pos;
             auto put = [&](int j, unsigned rec) {
-                if (j < mine && pos + j < cap_part) {
-                    const unsigned q = rec & 15u;
-                    const int h = ((rec & 16u) ? hb1 : hb0) + static_cast<int>(8u * (q >> 2) + (q & 3u));
-                    list[pos + j] = make_uint2(__float_as_uint(__uint_as_float(rec & 0xFFFFFFE0u) * inv_r), static_cast<unsigned>(h));
+                if (j < lim) {
+                    const int h = ((rec & 32u) ? hb1 : hb0) + static_cast<int>(rec & 63u);
+                    wp[j] = make_uint2(__float_as_uint(__uint_as_float(rec & 0xFFFFFFC0u) * inv_r), static_cast<unsigned>(h));
                 }
             };
             // slot j holds a record only for lanes with more than j of them: stop at the first empty level
@@ -350,7 +355,8 @@ sweep_xstat_f16_kernel(XsArgs a) {
     // their record and advance their write position; EXEC <- all.  After every fourth value the position is clamped.
     auto filter_value = [&](int mt, int q) {
         const float v = acc[mt][q];                          // latent * rinv (the chain started from bias * rinv)
-        const unsigned rec = (__float_as_uint(v) & 0xFFFFFFE0u) | static_cast<unsigned>(mt * 16 + q);
+        // the low six mantissa bits make room for the value's place inside the block: row tile, accumulator quad, register
+        const unsigned rec = (__float_as_uint(v) & 0xFFFFFFC0u) | static_cast<unsigned>(mt * 32 + 8 * (q >> 2) + (q & 3));
         const float cmp = (ABL == 1 || ABL == 7) ? __builtin_huge_valf() : thr_s;
         asm volatile("v_cmpx_nlt_f32_e32 vcc, %[v], %[thr]\n\t"
                      "ds_write_b32 %[addr], %[rec]\n\t"
