@@ -129,7 +129,8 @@ int qsae_encode_topk_latent(const float* x, const float* W, const float* bias, i
  * 32768); those survivors are re-evaluated with the exact fp32 fmaf chain and ranked exactly, so idx,
  * val and dense are bit-identical to qsae_encode_topk_latent.  Rows the bound cannot serve (non-finite
  * inputs, overflowing lists) go through the exact kernels.  Wq/meta come from qsae_prefilter_pack_w
- * (once per checkpoint: Wq = H*D fp16, meta = 4 device floats).  D % 64 == 0, D <= 2048; other shapes
+ * (once per checkpoint: Wq = H*D fp16, meta = 4 device floats -- weight scale, largest row norm, largest |bias|, largest
+ * distance between a row and its fp16 copy; opaque to the caller).  D % 64 == 0, D <= 2048; other shapes
  * return QSAE_ERR_UNSUPPORTED (use qsae_encode_topk_latent).  dense may be NULL.  For D in {128, 256, 512} the
  * candidate pass is one launch (activation rows stationary in registers, fp16 weights streamed once per workgroup)
  * that also derives the row thresholds and writes the zeros of `dense`; the survivors are written by the refinement.
