@@ -40,7 +40,9 @@ __device__ __forceinline__ void pref_row_params(float mx, float ss, float ee, in
     const float nrm = sqrtf(ss) * 1.0001f;           // covers the rounding of the fp32 sum of squares (<= D 2^-24 relative)
     float eps = __builtin_huge_valf();               // non-finite row or weights: everything is a candidate -> flagged
     inv = 0.f;
-    if (sx > 0.f && sw > 0.f && nrm < 3.0e38f && wn < 3.0e38f && fn < 3.0e38f && !(ee != ee) && ee < 3.0e38f) {
+    // (bmax sx sw: the sweep starts its chains from bias * s_x s_w -- a bias that overflows there makes the row unservable)
+    if (sx > 0.f && sw > 0.f && nrm < 3.0e38f && wn < 3.0e38f && fn < 3.0e38f && !(ee != ee) && ee < 3.0e38f &&
+        bmax * sx * sw < 3.0e38f) {
         const float sd = sqrtf(static_cast<float>(D));
         const float u = 5.9604645e-8f;                              // 2^-24
         // ||e||: measured, or 2^-11 ||x|| plus what subnormal flushing can add

@@ -630,6 +630,26 @@ def test_prefilter_degenerate_rows_fall_back(fused_path):
         assert torch.equal(dense2.view(torch.int32), dense.view(torch.int32))
 
 
+def test_prefilter_with_biases_beyond_the_scaled_range(fused_path):
+    """The sweep starts its MFMA chains from bias * s_x s_w (a power of two around 2^17 for these inputs): a bias that
+    overflows there cannot be represented in the candidate pass.  The error budget declares such rows unservable, so they
+    take the exact kernels -- and the outputs stay the oracle's, with the huge units on top."""
+    ops = _ops()
+    B, D, H, k = 300, 128, 4096, 16
+    x = S.activations(98, B, D)
+    W = S.xavier_uniform(98, H, D, stream=1)
+    bias = S.normal(98, (H,), stream=3, std=0.05)
+    bias[7] = 3.0e35
+    bias[11] = -3.0e35
+    info = {}
+    idx, val, dense = _prefilter(ops, x, W, bias, k, info=info)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
+    assert (host(idx)[:, 0] == 7).all() and info["flagged_rows"] == B
+
+
 def test_ablation_builds_of_the_encoder_run_clean_at_the_shape_that_once_faulted():
     """Round 1, 18:15-18:20: `tools/bench_ablate.py` (B=32768, D=512, H=16384) ended twice in a GPU memory-access fault
     (gpurun_out/abl3.log: address 0x3bf3daf5c000; abl4.log: address nil).  Cause: the ablated
