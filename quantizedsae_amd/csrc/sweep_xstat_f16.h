@@ -1,8 +1,10 @@
 // sweep_xstat_f16.h -- the fp16 candidate sweep with the activation panel stationary in registers.
 //
 // Role: the candidate pass of the prefilter pipeline (encode_topk.hip).  For every activation row b and every
-// hidden unit h it forms the approximate latent  v = fma(sum_k xq[b,k] wq[h,k], inv[b], bias[h])  with
-// v_mfma_f32_32x32x16_f16 and appends (v, h) to the row's candidate list when !(v < tau[b] - margin[b]).
+// hidden unit h it forms the approximate latent  v = bias[h] + inv[b] sum_k xq[b,k] wq[h,k]  with
+// v_mfma_f32_32x32x16_f16 (the chain of a row tile starts from bias / inv, so the accumulators are v / inv and are
+// compared with (tau[b] - margin[b]) / inv directly) and appends (v, h) to the row's candidate list when
+// !(v < tau[b] - margin[b]).
 // It returns no values of its own: the refine step recomputes every survivor with the exact fp32 chain.
 // The same launch (i) derives tau from a pilot pass over a stratified H/16 sample of the hidden units
 // (pilot_stages > 0), (ii) writes the zeros of the dense [B, H] latent, whose HBM traffic it hides.
@@ -18,13 +20,16 @@
 // LDS image of a buffer: row r = CPR 16-byte chunks; chunk j sits at position j ^ (r & 15), applied on the
 // DMA source address and on the fragment read: the four 16-lane groups of a ds_read_b128 (MI355X guide,
 // LDS table) each see 16 rows that are distinct mod 16, i.e. 16 distinct bank groups.
-// One iteration: flush of the previous records -> [32 MFMAs of row tile 0 | DMA pieces of the next block |
-// filter of the previous row tile 1] -> [32 MFMAs of row tile 1 | fill stores | filter of row tile 0] ->
+// One iteration (in-sweep-fill build): flush of the previous records -> [32 MFMAs of row tile 0 | DMA pieces of the
+// next block | filter of the previous row tile 1] -> [32 MFMAs of row tile 1 | fill stores | filter of row tile 0] ->
 // s_waitcnt vmcnt(#fill stores) -> s_barrier.  vmcnt retires loads, stores and LDS-DMA in issue order, and
 // the fill stores are the youngest operations of an iteration: the wait retires the DMA without waiting for
 // the stores.  Nothing else uses the vector memory counter inside the loops: the block's bias is DMA'd into
 // LDS with the weights, hits collect in per-lane LDS record slots and are flushed (list lengths in registers)
 // at the top of the next iteration, before its DMA.
+// The build without fill code (ABL 9, the product path at D = 512: the zeros come from a co-resident kernel) gives
+// the two waves of a SIMD different jobs: waves 0-3 flush at the top, issue ALL DMA pieces of the next block during
+// their first pass (two per MFMA group); waves 4-7 issue none and flush between their two passes -- see `iteration`.
 #pragma once
 
 #include "gemm_mfma_f32_dma.h"
