@@ -1125,7 +1125,8 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
 // Same-process scans, ms per step (in-sweep fill: 4.75-4.92):  1024 waves x pace 3 | 4 | 5 | 6: 4.53 | 4.41 | 4.53 | 4.75;
 // 768 x 2: 4.43; 640 x 1: 4.44; unpaced 384-448: 4.51; a first version with a 64-bit division per store (which paced
 // it by accident), 640 waves: 4.41-4.55.  All land on 2.53-2.57 ms for the sweep / fill pair against 2.23 ms for the
-// sweep alone: what is left is the memory system, not issue slots.
+// sweep alone: what is left is the memory system, not issue slots.  Round 2, sweep at 2.31 ms: pair time at 1024 waves x pace
+// 2 | 3 | 4: 2.34 | 2.30 | 2.45 ms; 896 | 768 waves x pace 3: 2.43 | 2.60 ms (the pace has to follow the sweep).
 __global__ void __launch_bounds__(64)
 fill_zero_co_kernel(float* __restrict__ dense, long long ld, int rows, int ppr /* 1-KiB pieces per row */, int pace) {
     // piece p = (row r, 1-KiB column block c), p = blockIdx.x, += gridDim.x.  Everything but the lane offset is
