@@ -663,8 +663,9 @@ pref_w_err_kernel(const float* __restrict__ W, int H, int D, const float* __rest
 template <int NV>
 __global__ void __launch_bounds__(256)
 pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ meta,
-                   _Float16* __restrict__ xq, float* __restrict__ inv, float* __restrict__ margin) {
+                   _Float16* __restrict__ xq, float* __restrict__ inv, float* __restrict__ margin, int* __restrict__ zero_word) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;   // the call's flagged-row counter (saves a memset launch)
     if (row >= B) return;
     const float* xr = x + static_cast<int64_t>(row) * D;
     _Float16* qr = xq + static_cast<int64_t>(row) * D;
@@ -728,13 +729,14 @@ pref_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __res
     }
 }
 
-static void launch_x_prep(const float* x, int B, int D, const float* meta, _Float16* xq, float* inv, float* margin, hipStream_t s) {
+static void launch_x_prep(const float* x, int B, int D, const float* meta, _Float16* xq, float* inv, float* margin, hipStream_t s,
+                          int* zero_word = nullptr) {
     const dim3 grid((B + 3) / 4), block(256);
     const bool vec = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(xq) % 8 == 0);
-    if (vec && D == 512) hipLaunchKernelGGL(pref_x_prep_kernel<2>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
-    else if (vec && D == 256) hipLaunchKernelGGL(pref_x_prep_kernel<1>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
-    else if (vec && D == 1024) hipLaunchKernelGGL(pref_x_prep_kernel<4>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
-    else hipLaunchKernelGGL(pref_x_prep_kernel<0>, grid, block, 0, s, x, B, D, meta, xq, inv, margin);
+    if (vec && D == 512) hipLaunchKernelGGL(pref_x_prep_kernel<2>, grid, block, 0, s, x, B, D, meta, xq, inv, margin, zero_word);
+    else if (vec && D == 256) hipLaunchKernelGGL(pref_x_prep_kernel<1>, grid, block, 0, s, x, B, D, meta, xq, inv, margin, zero_word);
+    else if (vec && D == 1024) hipLaunchKernelGGL(pref_x_prep_kernel<4>, grid, block, 0, s, x, B, D, meta, xq, inv, margin, zero_word);
+    else hipLaunchKernelGGL(pref_x_prep_kernel<0>, grid, block, 0, s, x, B, D, meta, xq, inv, margin, zero_word);
 }
 
 // pilot epilogue: approximate dense latents of the first P hidden units, rows = activations (registers),
@@ -1248,7 +1250,6 @@ static int prefilter_submit(const PrefCall& c) {
     float* inv = reinterpret_cast<float*>(ws + PL.inv);
     float* margin = reinterpret_cast<float*>(ws + PL.margin);
     int* cnt_parts = reinterpret_cast<int*>(ws + PL.cnt_parts);
-    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
     const bool xstat = pl.xstat, inkernel = pl.inkernel, fill_co = pl.fill_co, fill_in_sweep = pl.fill_in_sweep;
     float* fused_fill = xstat ? nullptr : c.dense;
     const int Hs = pl.Hs, hoff = pl.hoff, parts = pl.parts, cap_part = pl.cap_part;
@@ -1265,8 +1266,10 @@ static int prefilter_submit(const PrefCall& c) {
     //    this in its own prologue, straight into registers)
     const bool fuse_prep = inkernel && g_fuse_xprep;
     if (!fuse_prep && (g_x_phase & 1)) {
-        launch_x_prep(c.x, B, D, c.meta, xq, inv, margin, s);
+        launch_x_prep(c.x, B, D, c.meta, xq, inv, margin, s, flags);    // (also zeroes the flagged-row counter)
         QSAE_LAUNCH_CHECK();
+    } else {
+        QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
     }
     const int Kw = D / 2;                                    // 4-byte words per fp16 row
     const float* xq_w = reinterpret_cast<const float*>(xq);
