@@ -1752,6 +1752,23 @@ extern "C" int qsae_debug_prefilter_offsets(int B, int D, int H, int k, size_t* 
     if (pilot_cols) *pilot_cols = pilot_width(H);
     return QSAE_OK;
 }
+
+// test hook: where a prefilter call leaves the candidate lists in its workspace -- list entries [B][cap] {value bits, hidden
+// index}, segment lengths cnt[B] (part 0) and cnt_parts[(p - 1) B + b] (parts 1..), thresholds tau[B], margins [B]
+extern "C" int qsae_debug_prefilter_list_offsets(int B, int D, int H, int k, size_t* cand_off, size_t* cnt_off,
+                                                 size_t* cnt_parts_off, size_t* tau_off, size_t* margin_off, int* cap,
+                                                 int* parts) {
+    const FusedLayout L = fused_layout(B, D, H, k);
+    const PrefLayout PL = pref_layout(B, D, L.total);
+    if (cand_off) *cand_off = L.cand;
+    if (cnt_off) *cnt_off = L.cnt;
+    if (cnt_parts_off) *cnt_parts_off = PL.cnt_parts;
+    if (tau_off) *tau_off = L.tau;
+    if (margin_off) *margin_off = PL.margin;
+    if (cap) *cap = kCandCap;
+    if (parts) *parts = xstat_parts(B, H, kCandCap);
+    return QSAE_OK;
+}
 #endif  // QSAE_DEBUG_BUILD
 
 // Fraction of the encoder's 2 B D H FLOPs that the profiled sweep launch (qsae_profile_sweep_events) covers: with the

@@ -606,6 +606,59 @@ def test_prefilter_error_bound_holds_with_margin(fused_path):
     assert ratio.max() < 0.6, ratio.max()                  # the bound itself is ratio <= 1
 
 
+def test_candidate_lists_of_the_sweep_respect_the_error_budget(fused_path):
+    """What the candidate sweep leaves in the lists (in-kernel pilot, bias folded into the MFMA chain, records scaled back
+    at flush time): every entry's value is within eps_b of the exact chain of its hidden unit, every hidden unit whose
+    exact latent reaches tau - margin + eps_b is listed, nothing is listed twice."""
+    ops = _ops()
+    B, D, H, k = 520, 512, 8192, 65
+    x = S.activations(99, B, D)
+    x[::5] *= 30.0
+    x[1::5] *= 1e-3
+    W = S.xavier_uniform(99, H, D, stream=1)
+    bias = S.normal(99, (H,), stream=3, std=0.3)
+    idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx) and np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    lib = fused_path
+    offs = [C.c_size_t() for _ in range(5)]
+    cap, parts = C.c_int(), C.c_int()
+    lib.qsae_debug_prefilter_list_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 5 + [C.POINTER(C.c_int)] * 2
+    lib.qsae_debug_prefilter_list_offsets(B, D, H, k, *[C.byref(o) for o in offs], C.byref(cap), C.byref(parts))
+    cand_off, cnt_off, cntp_off, tau_off, mar_off = (o.value for o in offs)
+    cap, parts = cap.value, parts.value
+    ws = ops._workspace(torch.device(DEV), 1)             # this stream's scratch buffer, as the call above left it
+    cand = host(ws[cand_off: cand_off + B * cap * 8].view(torch.int32).reshape(B, cap, 2))
+    cnt0 = host(ws[cnt_off: cnt_off + B * 4].view(torch.int32))
+    cntp = host(ws[cntp_off: cntp_off + B * 4 * 7].view(torch.int32).reshape(7, B))
+    tau = host(ws[tau_off: tau_off + B * 4].view(torch.float32))
+    margin = host(ws[mar_off: mar_off + B * 4].view(torch.float32))
+    exact = oracle.encode(x, W, bias)
+    cap_part = cap // parts
+    worst = 0.0
+    for b in range(B):
+        hs, vs = [], []
+        for p in range(parts):
+            n = int(cnt0[b] if p == 0 else cntp[p - 1][b])
+            if n > cap_part:                               # overflowing rows are flagged: not this test's subject
+                hs = None
+                break
+            seg = cand[b, p * cap_part: p * cap_part + n]
+            vs.append(seg[:, 0].copy().view(np.float32))
+            hs.append(seg[:, 1])
+        if hs is None:
+            continue
+        hs, vs = np.concatenate(hs), np.concatenate(vs)
+        assert len(set(hs.tolist())) == len(hs) and hs.min(initial=0) >= 0 and hs.max(initial=0) < H
+        eps = margin[b] / 2.0
+        err = np.abs(vs.astype(np.float64) - exact[b, hs]).max(initial=0.0)
+        worst = max(worst, err / eps)
+        assert err <= eps, (b, err, eps)
+        must = np.nonzero(exact[b] >= tau[b] - margin[b] + eps)[0]
+        assert np.isin(must, hs).all(), b
+    assert worst > 0.0
+
+
 def test_prefilter_degenerate_rows_fall_back(fused_path):
     ops = _ops()
     B, D, H, k = 260, 64, 4096, 40
