@@ -1068,10 +1068,21 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     int* w_idx = reinterpret_cast<int*>(wt);
     float* w_val = reinterpret_cast<float*>(wt) + kRefMaxSurv;
     static_assert(2 * kRefMaxSurv * 4 <= 64 * kRefTileStride * 4, "winner arrays must fit the W tile");
+    // A hidden unit listed twice would give two survivors one key and one rank: a winner slot would stay unwritten and
+    // the decode below would gather with whatever it holds.  The sweep never lists a unit twice; a row whose list says
+    // otherwise is handed to the exact kernels like any other row the lists cannot serve -- after the loop: what it has
+    // written by then are exact values of true members of the top-k (a duplicate displaces one, it adds none), which the
+    // exact kernels write again.
+    bool twice = false;
     for (int j = lane; j < m; j += 64) {
         const unsigned long long mine = ekey[j];
-        int rank = 0;
-        for (int i = 0; i < m; ++i) rank += (ekey[i] > mine) ? 1 : 0;
+        int rank = 0, same = 0;
+        for (int i = 0; i < m; ++i) {
+            const unsigned long long other = ekey[i];
+            rank += (other > mine) ? 1 : 0;
+            same += (other == mine) ? 1 : 0;
+        }
+        twice |= same != 1;
         if (rank < k) {
             const int32_t hi = static_cast<int32_t>(key_index(mine));
             const float vv = reinterpret_cast<const float*>(hidx)[j];
@@ -1083,6 +1094,13 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                 w_val[rank] = vv;
             }
         }
+    }
+    if (__any(twice)) {
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+        return;
     }
     stamp(5);
     // ---- sparse decode of this row (BinarySAE): winners into ascending index order, then the fmaf chain over the

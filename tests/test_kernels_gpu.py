@@ -659,6 +659,49 @@ def test_candidate_lists_of_the_sweep_respect_the_error_budget(fused_path):
     assert worst > 0.0
 
 
+def test_refinement_hands_corrupted_lists_to_the_exact_kernels(fused_path):
+    """The refinement gathers with what the candidate lists say.  Lists that could not have come from the sweep -- a hidden
+    unit listed twice (two survivors with one key: a winner slot would stay unwritten and the row decode would gather
+    with it), an index outside the dictionary -- make it flag the row instead; the exact kernels then produce the row.
+    The debug build can run the two halves of a call separately, so the lists are edited in between."""
+    ops = _ops()
+    lib = fused_path
+    lib.qsae_debug_set_phases.argtypes = [C.c_int, C.c_int]
+    B, D, H, k = 520, 512, 8192, 65
+    x = S.activations(89, B, D)
+    W = S.xavier_uniform(89, H, D, stream=1)
+    bias = S.normal(89, (H,), stream=3, std=0.1)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    offs = [C.c_size_t() for _ in range(5)]
+    cap, parts = C.c_int(), C.c_int()
+    lib.qsae_debug_prefilter_list_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 5 + [C.POINTER(C.c_int)] * 2
+    lib.qsae_debug_prefilter_list_offsets(B, D, H, k, *[C.byref(o) for o in offs], C.byref(cap), C.byref(parts))
+    cand_off, cnt_off = offs[0].value, offs[1].value
+    try:
+        lib.qsae_debug_set_phases(1, 0)                    # activation preparation + candidate sweep only
+        _prefilter(ops, x, W, bias, k, want_dense=False)
+        torch.cuda.synchronize()
+        ws = ops._workspace(torch.device(DEV), 1)
+        cand = ws[cand_off: cand_off + B * cap.value * 8].view(torch.int32).reshape(B, cap.value, 2)
+        cnt0 = host(ws[cnt_off: cnt_off + B * 4].view(torch.int32))
+        assert (cnt0[:12] >= 2).all()
+        # rows 0-9: the row's best hidden unit (a certain survivor) written over the first two entries: listed twice or
+        # three times, with its exact value as the approximate one
+        top = torch.from_numpy(np.stack([want_val[:10, 0].view(np.int32), want_idx[:10, 0].astype(np.int32)], axis=1)).to(cand.device)
+        cand[0:10, 0, :] = top
+        cand[0:10, 1, :] = top
+        cand[10, 0, 1] = H + 5                             # row 10: a hidden index past the dictionary
+        cand[11, 0, 1] = -1                                # row 11: 0xFFFFFFFF
+        info = {}
+        lib.qsae_debug_set_phases(2, 0)                    # refinement (+ exact fallback) on the edited lists
+        idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False, info=info)
+    finally:
+        lib.qsae_debug_set_phases(3, 0)
+    assert info["flagged_rows"] >= 12
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+
+
 def test_prefilter_degenerate_rows_fall_back(fused_path):
     ops = _ops()
     B, D, H, k = 260, 64, 4096, 40
