@@ -128,7 +128,10 @@ def secondary_configs(device, x):
                                   TernarySparseAutoencoder)
     out = []
 
-    def run(name, model, call, rows, flops_per_row):
+    def run(name, model, call, rows, flops_per_row, submit=None):
+        """call(model, x): the blocking forward(), timed with one HIP-event pair per repetition (median) and by the wall
+        clock (ms_wall_mean: includes whatever the host waits for).  submit(model, x, slot): the two-call form where the
+        model has one -- two batches in flight, wall clock over the whole loop (ms_pipelined_wall_mean)."""
         model = model.to(device).eval()
         xb = x[:rows]
         reps = 10
@@ -143,14 +146,32 @@ def secondary_configs(device, x):
                 r = call(model, xb)
                 b.record()
             torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / reps * 1e3
-        gpu = sorted(a.elapsed_time(b) for a, b in evs)
-        ms = gpu[reps // 2]
+            wall = (time.perf_counter() - t0) / reps * 1e3
+            gpu = sorted(a.elapsed_time(b) for a, b in evs)
+            ms = gpu[reps // 2]
+            entry = {"config": name, "rows": rows, "ms_per_step": ms, "ms_min": gpu[0], "ms_max": gpu[-1],
+                     "ms_wall_mean": wall, "reps": reps, "timing": "blocking forward(): HIP events per repetition, median",
+                     "activations_per_s": rows / ms * 1e3, "algorithmic_tflops": flops_per_row * rows / ms / 1e9}
+            if submit is not None:
+                n = 2 * reps
+                pending = None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    h = submit(model, xb, i % 2)
+                    if pending is not None:
+                        r = pending.result()
+                    pending = h
+                r = pending.result()
+                torch.cuda.synchronize()
+                wall_p = (time.perf_counter() - t0) / n * 1e3
+                entry.update({"ms_pipelined_wall_mean": wall_p,
+                              "pipelined": "forward_submit / result, two batches in flight, wall clock over "
+                                           f"{n} steps (sync on both sides)",
+                              "activations_per_s_pipelined": rows / wall_p * 1e3})
         del r, model
         torch.cuda.empty_cache()
-        out.append({"config": name, "rows": rows, "ms_per_step": ms, "ms_min": gpu[0], "ms_max": gpu[-1],
-                    "ms_wall_mean": wall, "reps": reps, "timing": "HIP events per repetition, median",
-                    "activations_per_s": rows / ms * 1e3, "algorithmic_tflops": flops_per_row * rows / ms / 1e9})
+        out.append(entry)
 
     B = x.shape[0]
     with torch.no_grad():
@@ -164,7 +185,8 @@ def secondary_configs(device, x):
         m.decoder.weight_mirror.uniform_(-1, 1)
         run("config 4: QuantizedMatryoshkaSAE(512,32768,n_bits=4), 4 reconstruction levels, encoder bias -2.5 sigma "
             "(~200 active units per row): z bits from the fp16 candidate sweep + exact re-evaluation at the cutoff, "
-            "decoder walks the active units; bit-identical to the dense kernels", m, lambda mm, xx: mm(xx), B, 4.0 * D * H)
+            "decoder walks the active units; bit-identical to the dense kernels", m, lambda mm, xx: mm(xx), B, 4.0 * D * H,
+            submit=lambda mm, xx, sl: mm.forward_submit(xx, slot=sl))
         m.bits_path = "dense"
         m.decoder.SPARSE_MAX_ACTIVE_FRACTION = 0.0         # dense decoder whatever the activation density
         run("config 4, same model through the exact dense kernels only (fp32 MFMA encoder + dense decoder)", m,
@@ -175,14 +197,24 @@ def secondary_configs(device, x):
         run("config 4 at random init (encoder bias 0: half of the units fire, dense kernels)", m, lambda mm, xx: mm(xx),
             B, 4.0 * D * H)
         run("baseline_sae: BaselineSparseAutoencoder(512,32768) top-32", BaselineSparseAutoencoder(D, H),
-            lambda mm, xx: mm(xx), B, 2.0 * D * H + 2.0 * 32 * D)
+            lambda mm, xx: mm(xx), B, 2.0 * D * H + 2.0 * 32 * D, submit=lambda mm, xx, sl: mm.forward_submit(xx, slot=sl))
         m = ResidualQuantizedSAE(D, H, top_k=32, abs_range=1.5, n_bits=4)
         run("rq_sae: ResidualQuantizedSAE(512,32768,n_bits=4), random init (dense activations)", m, lambda mm, xx: mm(xx),
             min(B, 32768), 4.0 * D * H)
         m = BinarySAE(D, H, gamma=GAMMA, n_bits=N_BITS)
         m.decoder.weight.copy_(torch.where(torch.rand_like(m.decoder.weight) > 0.5, 30.0, -30.0))
         run("config 2, compact outputs (idx, val, reconstruction; no dense latent)", m,
-            lambda mm, xx: mm.forward_compact(xx), B, 2.0 * D * H + 2.0 * K_TOP * D)
+            lambda mm, xx: mm.forward_compact(xx), B, 2.0 * D * H + 2.0 * K_TOP * D,
+            submit=lambda mm, xx, sl: mm.forward_submit(xx, slot=sl, want_dense=False))
+        import warnings
+        m = BinarySAE(D, H, gamma=GAMMA, n_bits=N_BITS)
+        m.decoder.weight.normal_(0, 2.0)                   # not polarised: forward() = the reference's soft-integer arithmetic
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            run("config 2, unpolarised decoder (logit std 2): decode_mode auto -> the reference's soft sigmoid-bit integers "
+                "(sae/binary.py:26-38) from an fp32 [H,512] table, decoded by the refinement kernel (qsae_table_forward_prefilter); "
+                "dense latent + reconstruction", m, lambda mm, xx: mm(xx), B, 2.0 * D * H + 2.0 * K_TOP * D,
+                submit=lambda mm, xx, sl: mm.forward_submit(xx, slot=sl))
     return out
 
 
@@ -200,6 +232,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
                     help="batches in flight: 2 = submit step i+1 before finishing step i (qsae_prefilter_submit / _finish: "
                          "the 4-byte flagged-row read-back of a step no longer idles the GPU); 1 = blocking forward()")
+    ap.add_argument("--batches", type=int, default=4, help="distinct input batches the timed loop rotates over")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5,
+                    help="extra run of at least this many seconds of steps, reported under `sustained` (0 = skip; N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -229,33 +264,49 @@ def main():
     B = args.rows
     g = torch.Generator(device=device)
     g.manual_seed(1000 + rank)                       # every rank owns a different row shard
-    x = torch.randn((B, D), device=device, generator=g)
+    # the timed loop rotates over several distinct batches (step i takes batch i mod n): data-dependent work (survivors per
+    # row, rows that need the exact fallback) is not one replayed outcome
+    xs = [torch.randn((B, D), device=device, generator=g) for _ in range(max(1, args.batches))]
+    x = xs[0]
     model.decoder.packed()                           # pack once, outside the timed region
     sq = torch.zeros((), dtype=torch.float64, device=device)
 
-    def step(acc):
-        latent, recon, _pol = model(x)
-        ops.sq_err_sum(recon, x, acc)
+    def step(acc, i=0):
+        xi = xs[i % len(xs)]
+        latent, recon, _pol = model(xi)
+        ops.sq_err_sum(recon, xi, acc)
         return latent, recon
 
-    def run_steps(n_steps, acc):
-        """n_steps full forwards + MSE accumulation.  With --pipeline 2 step i+1's kernels are queued before step i's
-        flagged-row count is read (every step still completes inside the caller's timed region)."""
-        if args.pipeline <= 1:
-            for _ in range(n_steps):
-                step(acc)
+    def run_steps(n_steps, acc, pipeline=None, marks=None):
+        """n_steps full forwards + MSE accumulation.  pipeline 2: step i+1's kernels are queued before step i's
+        flagged-row count is read (every step still completes inside the caller's timed region); pipeline 1: the
+        blocking forward().  marks: optional list of n_steps + 1 timing events, one recorded per step on the launch
+        stream."""
+        pipeline = args.pipeline if pipeline is None else pipeline
+        if marks:
+            marks[0].record()
+        if pipeline <= 1:
+            for i in range(n_steps):
+                step(acc, i)
+                if marks:
+                    marks[i + 1].record()
             return
-        pending = None
+        pending, xprev = None, None
         for i in range(n_steps):
-            h = model.forward_submit(x, slot=i % 2)
+            xi = xs[i % len(xs)]
+            h = model.forward_submit(xi, slot=i % 2)
             if pending is not None:
                 _lat, rec, _pol = pending.result()
-                ops.sq_err_sum(rec, x, acc)
-            pending = h
+                ops.sq_err_sum(rec, xprev, acc)
+                if marks:
+                    marks[i].record()
+            pending, xprev = h, xi
         _lat, rec, _pol = pending.result()
-        ops.sq_err_sum(rec, x, acc)
+        ops.sq_err_sum(rec, xprev, acc)
+        if marks:
+            marks[n_steps].record()
 
-    def timed_region(n_steps, acc):
+    def timed_region(n_steps, acc, pipeline=None):
         """barrier + sync, n_steps forwards, sync + barrier; returns elapsed seconds (max over ranks) and
         the live HIP-event timing of the dominant sweep kernel."""
         ops.kernel_timer.reset()
@@ -265,7 +316,7 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        run_steps(n_steps, acc)
+        run_steps(n_steps, acc, pipeline)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -281,6 +332,64 @@ def main():
     mse = sharding.reduce_mse(sq, args.steps * B * D)
     path_used = model.resolved_latent_path(B)
 
+    # what drops in: the blocking call a user of the reference makes -- SAEWrapper.__call__(batch) -> outputs dict
+    # (inference/framework.py:316-319) -- same steps, same batches, same MSE accumulation; reported beside `value`
+    from quantizedsae_amd.inference.framework import SAE_REGISTRY, SAEWrapper
+    wrapper = SAEWrapper(SAE_REGISTRY["b_sae"], model, device)
+
+    def run_blocking(n_steps, acc):
+        for i in range(n_steps):
+            xi = xs[i % len(xs)]
+            outs = wrapper(xi)
+            ops.sq_err_sum(outs["reconstruction"], xi, acc)
+
+    run_blocking(1, torch.zeros((), dtype=torch.float64, device=device))
+    sq_b = torch.zeros((), dtype=torch.float64, device=device)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run_blocking(args.steps, sq_b)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el_block = sharding.max_over_ranks(time.perf_counter() - t0, device=device)
+    mse_block = sharding.reduce_mse(sq_b, args.steps * B * D)
+    flagged_last = int(model.last_flagged_rows)
+
+    # sustained: >= args.sustained_seconds of steps in one region, one event per step
+    sustained = None
+    if world == 1 and args.sustained_seconds > 0:
+        n_sus = max(args.steps, int(args.sustained_seconds / (elapsed / args.steps)) + 1)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_sus + 1)]
+        sq_s = torch.zeros((), dtype=torch.float64, device=device)
+        clocks = []
+
+        def sclk():
+            try:
+                import glob
+                for path in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                    for line in open(path):
+                        if "*" in line:
+                            return line.split(":")[1].replace("*", "").strip()
+            except OSError:
+                pass
+            return None
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(n_sus, sq_s, marks=marks)
+        clocks.append(sclk())                                  # (GPU still busy: the queue is one batch deep)
+        torch.cuda.synchronize()
+        el_sus = time.perf_counter() - t0
+        gaps = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(1, n_sus - 1))    # (first and last gaps are not whole steps)
+        sustained = {"steps": n_sus, "seconds": el_sus, "value": B * n_sus / el_sus, "unit": "activations/s",
+                     "ms_per_step_mean": el_sus / n_sus * 1e3, "ms_step_min": gaps[0], "ms_step_median": gaps[len(gaps) // 2],
+                     "ms_step_p99": gaps[min(len(gaps) - 1, int(len(gaps) * 0.99))], "ms_step_max": gaps[-1],
+                     "step_timing": "distance between per-step HIP events on the launch stream",
+                     "sclk_while_busy": clocks[0],
+                     "recon_mse": sharding.reduce_mse(sq_s, n_sus * B * D)}
+
     # the exact-fp32-only path, same model and batch, measured separately (not part of `value`)
     fp32_ref = None
     if path_used == "prefilter" and not args.no_fp32_reference:
@@ -288,7 +397,7 @@ def main():
         n_ref = max(3, min(args.steps, 5))
         step(torch.zeros((), dtype=torch.float64, device=device))
         sq_ref = torch.zeros((), dtype=torch.float64, device=device)
-        el_ref, (ms_ref, n_sw, fr_ref) = timed_region(n_ref, sq_ref)
+        el_ref, (ms_ref, n_sw, fr_ref) = timed_region(n_ref, sq_ref, pipeline=1)
         mse_ref = sharding.reduce_mse(sq_ref, n_ref * B * D)
         model.latent_path = args.latent_path
         ach = fr_ref * FLOPS_PER_ROW_ENCODER * B / (ms_ref * 1e-3) / 1e12 if n_sw else None
@@ -348,6 +457,14 @@ def main():
                                           "per-row error bound only selects ~80 candidate hidden units per row, which are then "
                                           "re-evaluated with the exact fp32 fmaf chain and ranked exactly (DESIGN.md 4.2b)")},
             "recon_mse": mse,
+            "forward_blocking": {"value": world * B * args.steps / el_block, "unit": "activations/s",
+                                 "ms_per_step": el_block / args.steps * 1e3, "steps": args.steps, "recon_mse": mse_block,
+                                 "what": "the same steps through the call a user of the reference makes: SAEWrapper.__call__(batch) "
+                                         "-> outputs dict (inference/framework.py:316-319), i.e. BinarySAE.forward() with its one "
+                                         "host round trip per batch (the flagged-row count); one batch in flight",
+                                 "flagged_rows_last_batch": flagged_last},
+            "sustained": sustained,
+            "input_batches": len(xs),
             "whole_path_tflops_per_gpu": value / world * FLOPS_PER_ROW / 1e12,
             "whole_path_vs_fp32_mfma_roofline": value / world * FLOPS_PER_ROW / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "whole_path_dense_gbps_per_gpu": value / world * BYTES_PER_ROW_DENSE / 1e9,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QSAE_ABI_VERSION 2
+#define QSAE_ABI_VERSION 3
 
 #define QSAE_OK 0
 #define QSAE_ERR_INVALID_ARG (-1)  /* null pointer, non-positive dim, misaligned pointer      */
@@ -66,6 +66,11 @@ int qsae_device_info(int* cu_count, char* arch, int arch_len);
  * co-resident fill kernel has joined, where there is one), then forgets them.  NULL, NULL clears a pending pair.
  * This is how bench.py times the dominant kernel live on the launch stream. */
 int qsae_profile_sweep_events(void* ev_begin, void* ev_end);
+/* The events for the call above, created / read / destroyed through the HIP runtime this library is linked against
+ * (timing enabled).  elapsed: QSAE_ERR_HIP while either event has not completed. */
+int qsae_profile_event_create(void** ev);
+int qsae_profile_event_destroy(void* ev);
+int qsae_profile_event_elapsed_ms(void* ev_begin, void* ev_end, float* ms);
 /* Fraction of the encoder's 2 B D H FLOPs that the profiled launch covers for hidden width H (1.0 when the sweep
  * derives its thresholds itself, else (H - pilot block) / H). */
 double qsae_profile_sweep_flop_fraction(int H);
@@ -184,6 +189,25 @@ int qsae_prefilter_finish(const float* x, const float* W, const float* bias, con
                           float* recon, void* workspace, size_t workspace_bytes, int flagged,
                           qsae_stream_t stream);
 
+/* The three calls above with an fp32 dictionary [H][D] (row h = the decoder's weights of hidden unit h) in place of the
+ * packed n-bit one: recon = scale * sum_j val_j table[idx_j] + dec_bias, the arithmetic of qsae_decode_table_sparse, done
+ * by the refinement kernel for every row it ranks.  Two users: BaselineSparseAutoencoder.forward (sae/baseline.py:17-31;
+ * table = decoder.weight transposed, scale = 1) and BinarySAE.forward on a checkpoint whose decoder logits are not
+ * polarised (sae/binary.py:24-47 with the soft integers of :26-35; table = qsae_binary_soft_table, scale =
+ * quantization step).  table and recon 16-byte aligned; otherwise as above. */
+int qsae_table_forward_prefilter(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                 int B, int D, int H, int k, const float* table, float scale, const float* dec_bias,
+                                 int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon, void* workspace,
+                                 size_t workspace_bytes, int spec_rows, int* flagged_rows, qsae_stream_t stream);
+int qsae_prefilter_submit_table(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                int B, int D, int H, int k, const float* table, float scale, const float* dec_bias,
+                                int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon, void* workspace,
+                                size_t workspace_bytes, int* flagged_host, qsae_stream_t stream);
+int qsae_prefilter_finish_table(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                int B, int D, int H, int k, const float* table, float scale, const float* dec_bias,
+                                int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon, void* workspace,
+                                size_t workspace_bytes, int flagged, qsae_stream_t stream);
+
 /* dense[b][h] = val if (b,h) selected else +0; dense [B][ld].  Replaces zeros_like+scatter_. */
 int qsae_densify(const int32_t* idx, const float* val, int B, int k, int H, float* dense, int64_t ld,
                  qsae_stream_t stream);
@@ -260,6 +284,15 @@ size_t qsae_encode_bits_prefilter_workspace_bytes(int B, int D, int H);
 int qsae_encode_bits_prefilter(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
                                int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
                                size_t workspace_bytes, int* flagged_rows, qsae_stream_t stream);
+/* The same in two calls (see qsae_prefilter_submit / _finish): submit enqueues everything up to the bit resolution and the
+ * asynchronous copy of the flagged-row count into *flagged_host; finish, given that count, enqueues the exact dense kernel
+ * for those rows.  Bits of unflagged rows are final after submit; workspace untouched in between. */
+int qsae_encode_bits_prefilter_submit(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                      int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                      size_t workspace_bytes, int* flagged_host, qsae_stream_t stream);
+int qsae_encode_bits_prefilter_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                      int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                      size_t workspace_bytes, int flagged, qsae_stream_t stream);
 /* Hidden-major dictionary for the sparse decoder: codes_rows[j][ceil(D/16)] uint32, 2-bit two's-complement
  * fields of S_j/2 (same S as qsae_pack_matryoshka). */
 int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,

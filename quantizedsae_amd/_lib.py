@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ["QSAE_HIP_LIB"]) if os.environ.get("QSAE_HIP_LIB") el
 # The debug build (same sources + -DQSAE_DEBUG_BUILD): process-wide qsae_debug_* switches and ablation kernels.  Never
 # loaded by the package itself; tools/ and a few tests ask for it explicitly (use_library("debug")).
 DEBUG_LIB_PATH = _PKG / "lib" / "libqsae_hip_debug.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4
@@ -31,6 +31,9 @@ SIGNATURES = {
     "qsae_last_error": (C.c_char_p, []),
     "qsae_device_info": (_i, [C.POINTER(_i), C.c_char_p, _i]),
     "qsae_profile_sweep_events": (_i, [_vp, _vp]),
+    "qsae_profile_event_create": (_i, [C.POINTER(_vp)]),
+    "qsae_profile_event_destroy": (_i, [_vp]),
+    "qsae_profile_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
     "qsae_profile_sweep_flop_fraction": (C.c_double, [_i]),
     "qsae_kperm_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "qsae_encode_dense": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
@@ -52,6 +55,12 @@ SIGNATURES = {
                                     _vp, _sz, _vp, _vp]),
     "qsae_prefilter_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _i64, _vp,
                                     _vp, _sz, _i, _vp]),
+    "qsae_table_forward_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _i64, _vp,
+                                           _vp, _sz, _i, C.POINTER(_i), _vp]),
+    "qsae_prefilter_submit_table": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _i64, _vp,
+                                          _vp, _sz, _vp, _vp]),
+    "qsae_prefilter_finish_table": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _i64, _vp,
+                                          _vp, _sz, _i, _vp]),
     "qsae_densify": (_i, [_vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_binary_row_bytes": (_i, [_i, _i]),
     "qsae_pack_binary": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -66,6 +75,8 @@ SIGNATURES = {
     "qsae_decode_matryoshka": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_encode_bits_prefilter_workspace_bytes": (_sz, [_i, _i, _i]),
     "qsae_encode_bits_prefilter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, C.POINTER(_i), _vp]),
+    "qsae_encode_bits_prefilter_submit": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, _vp, _vp]),
+    "qsae_encode_bits_prefilter_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, _i, _vp]),
     "qsae_pack_matryoshka_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "qsae_decode_matryoshka_sparse": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_pack_bits_gt": (_i, [_vp, _i64, _i, _i, _f, _vp, _i64, _vp]),

@@ -151,53 +151,22 @@ decode_binary_sparse_kernel(const int32_t* __restrict__ idx, const float* __rest
     decode_row_sorted<FW>(s_idx, s_val, k, d, b, lane);
 }
 
+// rows != nullptr: row b of this launch is activation row rows[b] (as above)
 __global__ void __launch_bounds__(64 * kDecWaves)
-decode_table_sparse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val, int B, int k,
-                           const float* __restrict__ table, int H, int D, float scale,
-                           const float* __restrict__ bias, float* __restrict__ recon) {
+decode_table_sparse_kernel(const int32_t* __restrict__ idx, const float* __restrict__ val, int B, int k, int H,
+                           RowDecode d, const int* __restrict__ rows) {
     __shared__ DecShared sh;
     __shared__ int tmp_idx[kDecWaves][kDecMaxK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x * kDecWaves + wave;
-    const bool active = b < B;
+    const int slot = blockIdx.x * kDecWaves + wave;
+    const bool active = slot < B;
+    const long long b = active ? (rows ? rows[slot] : slot) : 0;
     int* s_idx = sh.idx[wave];
     float* s_val = sh.val[wave];
-    const long long off = active ? static_cast<long long>(b) * k : 0;
+    const long long off = b * k;
     sort_pairs_by_index(active, idx + off, val + off, k, H, lane, s_idx, s_val, tmp_idx[wave]);
     if (!active) return;
-    const int D4 = D / 4;
-    const bool mul = (scale != 1.0f);
-    for (int c = lane; c < D4; c += 64) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int j = 0;
-        for (; j + 4 <= k; j += 4) {
-            f32x4 w[4];
-            float a[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                w[u] = *reinterpret_cast<const f32x4*>(table + static_cast<long long>(s_idx[j + u]) * D + 4 * c);
-                a[u] = s_val[j + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(a[u], w[u][e], acc[e]);
-        }
-        for (; j < k; ++j) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(table + static_cast<long long>(s_idx[j]) * D + 4 * c);
-            const float a = s_val[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, w[e], acc[e]);
-        }
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float r = mul ? scale * acc[e] : acc[e];
-            r = r + (bias ? bias[4 * c + e] : 0.0f);
-            o[e] = r;
-        }
-        *reinterpret_cast<f32x4*>(recon + static_cast<long long>(b) * D + 4 * c) = o;
-    }
+    decode_row_table(s_idx, s_val, k, d, b, lane);
 }
 
 }  // namespace qsae
@@ -259,6 +228,11 @@ int decode_binary_sparse_rows(const int* rows, int nrows, const int32_t* idx, co
                               const RowDecode& d, hipStream_t s) {
     if (nrows <= 0) return QSAE_OK;
     const dim3 grid((nrows + kDecWaves - 1) / kDecWaves), block(64 * kDecWaves);
+    if (d.table) {          // fp32 dictionary rows (Baseline, BinarySAE soft integers)
+        hipLaunchKernelGGL(decode_table_sparse_kernel, grid, block, 0, s, idx, val, nrows, k, H, d, rows);
+        QSAE_LAUNCH_CHECK();
+        return QSAE_OK;
+    }
     switch (d.fw) {
         case 1: hipLaunchKernelGGL(decode_binary_sparse_kernel<1>, grid, block, 0, s, idx, val, nrows, k, H, d, rows); break;
         case 2: hipLaunchKernelGGL(decode_binary_sparse_kernel<2>, grid, block, 0, s, idx, val, nrows, k, H, d, rows); break;
@@ -280,7 +254,7 @@ extern "C" int qsae_decode_binary_sparse(const int32_t* idx, const float* val, i
     QSAE_CHECK_ARG(k >= 1, "k >= 1 required");
     QSAE_CHECK_SUPPORTED(k <= kDecMaxK, "k <= 256");
     const RowDecode d{reinterpret_cast<const uint32_t*>(packed), qsae_binary_row_bytes(D, n_bits) / 4, n_bits,
-                      field_width(n_bits), D, step, bias, recon};
+                      field_width(n_bits), D, step, bias, recon, nullptr};
     return decode_binary_sparse_rows(nullptr, B, idx, val, k, H, d, as_stream(stream));
 }
 
@@ -294,9 +268,6 @@ extern "C" int qsae_decode_table_sparse(const int32_t* idx, const float* val, in
     QSAE_CHECK_SUPPORTED(k <= kDecMaxK, "k <= 256");
     QSAE_CHECK_SUPPORTED(D % 4 == 0, "D must be a multiple of 4");
     QSAE_CHECK_ARG(aligned16(table) && aligned16(recon), "table and recon must be 16-byte aligned");
-    const dim3 grid((B + kDecWaves - 1) / kDecWaves), block(64 * kDecWaves);
-    hipLaunchKernelGGL(decode_table_sparse_kernel, grid, block, 0, as_stream(stream), idx, val, B, k, table, H, D,
-                       scale, bias, recon);
-    QSAE_LAUNCH_CHECK();
-    return QSAE_OK;
+    const RowDecode d{nullptr, 0, 0, 0, D, scale, bias, recon, table};
+    return decode_binary_sparse_rows(nullptr, B, idx, val, k, H, d, as_stream(stream));
 }

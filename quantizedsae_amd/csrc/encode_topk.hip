@@ -1089,7 +1089,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
             idx_out[static_cast<int64_t>(b) * k + rank] = hi;
             val_out[static_cast<int64_t>(b) * k + rank] = vv;
             if (dense) dense[static_cast<int64_t>(b) * dense_ld + hi] = vv;      // latent * mask; zeros are already there
-            if (dec.packed) {
+            if (dec.active()) {
                 w_idx[rank] = hi;
                 w_val[rank] = vv;
             }
@@ -1106,7 +1106,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     // ---- sparse decode of this row (BinarySAE): winners into ascending index order, then the fmaf chain over the
     // k dictionary rows.  Same code as the stand-alone decode kernel; here its gathers and integer converts run in
     // the issue slots the other waves' chain gathers leave idle.
-    if (dec.packed) {
+    if (dec.active()) {
         lds_handoff();
         int* s_idx = reinterpret_cast<int*>(ekey);                       // the exact keys are no longer needed
         float* s_val = reinterpret_cast<float*>(ekey) + kRefMaxSurv;
@@ -1368,7 +1368,7 @@ static int prefilter_submit(const PrefCall& c) {
         hipLaunchKernelGGL(kern, dim3((B + kRefWaves - 1) / kRefWaves), dim3(64 * kRefWaves), lds, s, cand,
                            cnt, kCandCap, tau, margin, c.x, c.W, c.bias, B, D, H, k, c.idx, c.val, flags, g_ref_ablate, g_ref_stamps,
                            pl.filled, c.dense_ld, parts, cnt_parts,
-                           c.dec ? *c.dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr});
+                           c.dec ? *c.dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr});
     }
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
@@ -1622,9 +1622,10 @@ static bool bits_prefilter_shape_ok(int B, int D, int H) {
            bits_lds_per_wave(H) * kBitsWaves <= 160 * 1024;
 }
 
-static int run_bits_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
-                              int B, int D, int H, uint32_t* zbits, int64_t words_ld, char* ws, qsae_stream_t stream,
-                              int* flagged_rows) {
+// Everything up to and including the bit resolution; afterwards flags[0] (device) = rows that need the exact dense
+// kernel, flags[1..] their ids, every other row's bits are final.
+static int bits_submit(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
+                       int B, int D, int H, uint32_t* zbits, int64_t words_ld, char* ws, qsae_stream_t stream) {
     hipStream_t s = as_stream(stream);
     const SweepProfile prof = take_sweep_profile();
     const BitsLayout L = bits_layout(B, D, H);
@@ -1651,23 +1652,22 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
     int rc = launch_xstat(D, xa, s, D == 512 ? 9 : 0);      // (nothing to zero-fill here: the build without fill code)
     if (prof.end) QSAE_HIP(hipEventRecord(prof.end, s));
     if (rc != QSAE_OK) return rc;
-    {
-        const size_t lds = bits_lds_per_wave(H) * kBitsWaves;
-        QSAE_SET_MAX_LDS_ONCE(resolve_bits_kernel, 160 * 1024);
-        hipLaunchKernelGGL(resolve_bits_kernel, dim3((B + kBitsWaves - 1) / kBitsWaves), dim3(64 * kBitsWaves), lds, s,
-                           cand, cnt, kBitsCap, parts, cnt_parts, margin, x, W, bias, B, D, H, zbits, words_ld, flags);
-        QSAE_LAUNCH_CHECK();
-    }
-    // flagged rows: exact dense kernel on the gathered rows (the count comes back through this thread's pinned word)
-    ThreadDeviceCtx* ctx = nullptr;
-    rc = thread_device_ctx(&ctx);
-    if (rc != QSAE_OK) return rc;
-    *ctx->pinned = 0;
-    QSAE_HIP(hipMemcpyAsync(ctx->pinned, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    QSAE_HIP(hipEventRecord(ctx->ev_copied, s));
-    QSAE_HIP(hipEventSynchronize(ctx->ev_copied));
-    const int nflag = *ctx->pinned;
-    if (flagged_rows) *flagged_rows = nflag;
+    const size_t lds = bits_lds_per_wave(H) * kBitsWaves;
+    QSAE_SET_MAX_LDS_ONCE(resolve_bits_kernel, 160 * 1024);
+    hipLaunchKernelGGL(resolve_bits_kernel, dim3((B + kBitsWaves - 1) / kBitsWaves), dim3(64 * kBitsWaves), lds, s,
+                       cand, cnt, kBitsCap, parts, cnt_parts, margin, x, W, bias, B, D, H, zbits, words_ld, flags);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+// The exact dense kernel on the nflag flagged rows (count known to the host).
+static int bits_finish(const float* x, const float* W, const float* bias, int B, int D, int H, uint32_t* zbits,
+                       int64_t words_ld, char* ws, qsae_stream_t stream, int nflag) {
+    if (nflag < 0 || nflag > B) return fail(QSAE_ERR_INVALID_ARG, "%s: flagged-row count out of range", __func__);
+    hipStream_t s = as_stream(stream);
+    const BitsLayout L = bits_layout(B, D, H);
+    const int* flags = reinterpret_cast<const int*>(ws + L.flags);
+    const int words = (H + 31) / 32;
     float* fx = reinterpret_cast<float*>(ws + L.fx);
     uint32_t* fbits = reinterpret_cast<uint32_t*>(ws + L.fbits);
     for (int f0 = 0; f0 < nflag; f0 += kBitsChunk) {
@@ -1677,7 +1677,7 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
         hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, x, rows, n,
                            D, fx);
         QSAE_LAUNCH_CHECK();
-        rc = qsae_encode_bits(fx, W, bias, n, D, H, fbits, words, stream);
+        const int rc = qsae_encode_bits(fx, W, bias, n, D, H, fbits, words, stream);
         if (rc != QSAE_OK) return rc;
         const long long tw = static_cast<long long>(n) * words;
         hipLaunchKernelGGL(scatter_bit_rows_kernel, dim3(static_cast<unsigned>((tw + 255) / 256)), dim3(256), 0, s, fbits,
@@ -1685,6 +1685,27 @@ static int run_bits_prefilter(const float* x, const float* W, const float* bias,
         QSAE_LAUNCH_CHECK();
     }
     return QSAE_OK;
+}
+
+// Blocking form: submit, the count through this thread's pinned word (one host round trip), finish.
+static int run_bits_prefilter(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
+                              int B, int D, int H, uint32_t* zbits, int64_t words_ld, char* ws, qsae_stream_t stream,
+                              int* flagged_rows) {
+    hipStream_t s = as_stream(stream);
+    int rc = bits_submit(x, W, bias, Wq, meta, B, D, H, zbits, words_ld, ws, stream);
+    if (rc != QSAE_OK) return rc;
+    const BitsLayout L = bits_layout(B, D, H);
+    ThreadDeviceCtx* ctx = nullptr;
+    rc = thread_device_ctx(&ctx);
+    if (rc != QSAE_OK) return rc;
+    *ctx->pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(ctx->pinned, ws + L.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipEventRecord(ctx->ev_copied, s));
+    QSAE_HIP(hipEventSynchronize(ctx->ev_copied));
+    const int nflag = *ctx->pinned;
+    if (flagged_rows) *flagged_rows = nflag;
+    if (nflag < 0 || nflag > B) return fail(QSAE_ERR_HIP, "%s: corrupt flagged-row count", __func__);
+    return bits_finish(x, W, bias, B, D, H, zbits, words_ld, ws, stream, nflag);
 }
 
 }  // namespace qsae
@@ -1883,7 +1904,8 @@ extern "C" size_t qsae_encode_topk_prefilter_workspace_bytes(int B, int D, int H
 static int prefilter_call(const char* who, const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
                           int B, int D, int H, int k, const uint8_t* packed, int n_bits, float step, const float* dec_bias,
                           int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon, void* workspace,
-                          size_t workspace_bytes, qsae_stream_t stream, PrefCall& call, RowDecode& dec) {
+                          size_t workspace_bytes, qsae_stream_t stream, PrefCall& call, RowDecode& dec,
+                          const float* table = nullptr) {
     if (!(x && W && Wq && meta && idx && val && workspace)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: null pointer", who);
     if (!(k >= 1 && k <= H)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: 1 <= k <= H required", who);
     if (!prefilter_shape_ok(B, D, H, k))
@@ -1902,7 +1924,13 @@ static int prefilter_call(const char* who, const float* x, const float* W, const
         if ((reinterpret_cast<uintptr_t>(packed) & 3u) != 0)
             return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: packed must be 4-byte aligned", who);
         dec = RowDecode{reinterpret_cast<const uint32_t*>(packed), qsae_binary_row_bytes(D, n_bits) / 4, n_bits,
-                        field_width(n_bits), D, step, dec_bias, recon};
+                        field_width(n_bits), D, step, dec_bias, recon, nullptr};
+        call.dec = &dec;
+    } else if (table) {     // fp32 dictionary rows; `step` is the scale
+        if (!recon) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: table given without recon", who);
+        if (!(aligned16(table) && aligned16(recon)))
+            return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: table and recon must be 16-byte aligned", who);
+        dec = RowDecode{nullptr, 0, 0, 0, D, step, dec_bias, recon, table};
         call.dec = &dec;
     }
     return QSAE_OK;
@@ -1976,6 +2004,58 @@ extern "C" int qsae_prefilter_finish(const float* x, const float* W, const float
     return prefilter_finish(call, /*first=*/0, flagged);
 }
 
+extern "C" int qsae_table_forward_prefilter(const float* x, const float* W, const float* bias, const void* Wq,
+                                           const float* meta, int B, int D, int H, int k, const float* table, float scale,
+                                           const float* dec_bias, int32_t* idx, float* val, float* dense, int64_t dense_ld,
+                                           float* recon, void* workspace, size_t workspace_bytes, int spec_rows,
+                                           int* flagged_rows, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (flagged_rows) *flagged_rows = 0;
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(table && recon, "null pointer");
+    PrefCall call;
+    RowDecode dec;
+    const int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, nullptr, 0, scale, dec_bias, idx, val, dense,
+                                  dense_ld, recon, workspace, workspace_bytes, stream, call, dec, table);
+    if (rc != QSAE_OK) return rc;
+    return run_prefilter(call, spec_rows, flagged_rows);
+}
+
+extern "C" int qsae_prefilter_submit_table(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                           int B, int D, int H, int k, const float* table, float scale, const float* dec_bias,
+                                           int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon,
+                                           void* workspace, size_t workspace_bytes, int* flagged_host, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    QSAE_CHECK_ARG(flagged_host != nullptr, "flagged_host must point to a host int");
+    if (B == 0) { *flagged_host = 0; return QSAE_OK; }
+    QSAE_CHECK_ARG(table && recon, "null pointer");
+    PrefCall call;
+    RowDecode dec;
+    int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, nullptr, 0, scale, dec_bias, idx, val, dense,
+                            dense_ld, recon, workspace, workspace_bytes, stream, call, dec, table);
+    if (rc != QSAE_OK) return rc;
+    rc = prefilter_submit(call);
+    if (rc != QSAE_OK) return rc;
+    const PrefPlan pl = pref_plan(call);
+    QSAE_HIP(hipMemcpyAsync(flagged_host, call.ws + pl.L.flags, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+    return QSAE_OK;
+}
+
+extern "C" int qsae_prefilter_finish_table(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                           int B, int D, int H, int k, const float* table, float scale, const float* dec_bias,
+                                           int32_t* idx, float* val, float* dense, int64_t dense_ld, float* recon,
+                                           void* workspace, size_t workspace_bytes, int flagged, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(table && recon, "null pointer");
+    PrefCall call;
+    RowDecode dec;
+    const int rc = prefilter_call(__func__, x, W, bias, Wq, meta, B, D, H, k, nullptr, 0, scale, dec_bias, idx, val, dense,
+                                  dense_ld, recon, workspace, workspace_bytes, stream, call, dec, table);
+    if (rc != QSAE_OK) return rc;
+    return prefilter_finish(call, /*first=*/0, flagged);
+}
+
 extern "C" size_t qsae_encode_bits_prefilter_workspace_bytes(int B, int D, int H) {
     if (!bits_prefilter_shape_ok(B, D, H)) return 0;
     return bits_layout(B, D, H).total;
@@ -1996,4 +2076,46 @@ extern "C" int qsae_encode_bits_prefilter(const float* x, const float* W, const 
     QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
     return run_bits_prefilter(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld,
                               static_cast<char*>(workspace), stream, flagged_rows);
+}
+
+/* the two-call form (see qsae_prefilter_submit / _finish) */
+static int bits_args_ok(const char* who, const float* x, const float* W, const void* Wq, const float* meta, int B, int D, int H,
+                        const uint32_t* zbits, int64_t words_ld, const void* workspace, size_t workspace_bytes) {
+    if (!(x && W && Wq && meta && zbits)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: null pointer", who);
+    if (words_ld < (H + 31) / 32) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: words_ld < ceil(H/32)", who);
+    if (!bits_prefilter_shape_ok(B, D, H))
+        return fail(QSAE_ERR_UNSUPPORTED, "%s: unsupported: shape not covered by the fp16 candidate sweep (D in {128,256,512}, H %% 64 == 0)", who);
+    if (!(aligned16(x) && aligned16(W) && aligned16(Wq)))
+        return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: x, W and Wq must be 16-byte aligned", who);
+    if (!(workspace && workspace_bytes >= bits_layout(B, D, H).total))
+        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", who);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
+        return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: workspace must be 256-byte aligned", who);
+    return QSAE_OK;
+}
+
+extern "C" int qsae_encode_bits_prefilter_submit(const float* x, const float* W, const float* bias, const void* Wq,
+                                                 const float* meta, int B, int D, int H, uint32_t* zbits, int64_t words_ld,
+                                                 void* workspace, size_t workspace_bytes, int* flagged_host,
+                                                 qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    QSAE_CHECK_ARG(flagged_host != nullptr, "flagged_host must point to a host int");
+    if (B == 0) { *flagged_host = 0; return QSAE_OK; }
+    int rc = bits_args_ok(__func__, x, W, Wq, meta, B, D, H, zbits, words_ld, workspace, workspace_bytes);
+    if (rc != QSAE_OK) return rc;
+    char* ws = static_cast<char*>(workspace);
+    rc = bits_submit(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld, ws, stream);
+    if (rc != QSAE_OK) return rc;
+    QSAE_HIP(hipMemcpyAsync(flagged_host, ws + bits_layout(B, D, H).flags, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+    return QSAE_OK;
+}
+
+extern "C" int qsae_encode_bits_prefilter_finish(const float* x, const float* W, const float* bias, const void* Wq,
+                                                 const float* meta, int B, int D, int H, uint32_t* zbits, int64_t words_ld,
+                                                 void* workspace, size_t workspace_bytes, int flagged, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (B == 0) return QSAE_OK;
+    const int rc = bits_args_ok(__func__, x, W, Wq, meta, B, D, H, zbits, words_ld, workspace, workspace_bytes);
+    if (rc != QSAE_OK) return rc;
+    return bits_finish(x, W, bias, B, D, H, zbits, words_ld, static_cast<char*>(workspace), stream, flagged);
 }

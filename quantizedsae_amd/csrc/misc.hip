@@ -16,15 +16,31 @@ int thread_device_ctx(ThreadDeviceCtx** out) {
     static thread_local std::map<int, ThreadDeviceCtx> table;
     int dev = -1;
     QSAE_HIP(hipGetDevice(&dev));
-    ThreadDeviceCtx& c = table[dev];
-    if (!c.side) {
-        QSAE_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
-        QSAE_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-        QSAE_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
-        QSAE_HIP(hipEventCreateWithFlags(&c.ev_copied, hipEventDisableTiming));
-        QSAE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(int), hipHostMallocDefault));
+    auto it = table.find(dev);
+    if (it == table.end()) {
+        // built in a local object and entered into the table only when all five parts exist: a failure half-way (event
+        // creation, page-locked memory under pressure) leaves no entry behind that later calls would take for complete
+        ThreadDeviceCtx c{};
+        auto undo = [&c]() {
+            if (c.pinned) (void)hipHostFree(c.pinned);
+            if (c.ev_copied) (void)hipEventDestroy(c.ev_copied);
+            if (c.ev_join) (void)hipEventDestroy(c.ev_join);
+            if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+            if (c.side) (void)hipStreamDestroy(c.side);
+        };
+        hipError_t e = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c.pinned), sizeof(int), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            undo();
+            snprintf(last_error_buf(), 512, "%s: creating the per-thread helper objects failed: %s", __func__, hipGetErrorString(e));
+            return QSAE_ERR_HIP;
+        }
+        it = table.emplace(dev, c).first;
     }
-    *out = &c;
+    *out = &it->second;
     return QSAE_OK;
 }
 
@@ -255,6 +271,27 @@ extern "C" int qsae_abi_version(void) { return QSAE_ABI_VERSION; }
 extern "C" int qsae_profile_sweep_events(void* ev_begin, void* ev_end) {
     t_sweep_profile.begin = static_cast<hipEvent_t>(ev_begin);
     t_sweep_profile.end = static_cast<hipEvent_t>(ev_end);
+    return QSAE_OK;
+}
+
+// Timing events created and read through THIS library's HIP runtime (the one that records them): a caller that dlopens
+// a HIP runtime of its own may get a second copy whose events the recording side does not know.
+extern "C" int qsae_profile_event_create(void** ev) {
+    QSAE_CHECK_ARG(ev != nullptr, "null pointer");
+    hipEvent_t e = nullptr;
+    QSAE_HIP(hipEventCreate(&e));
+    *ev = e;
+    return QSAE_OK;
+}
+
+extern "C" int qsae_profile_event_destroy(void* ev) {
+    if (ev) QSAE_HIP(hipEventDestroy(static_cast<hipEvent_t>(ev)));
+    return QSAE_OK;
+}
+
+extern "C" int qsae_profile_event_elapsed_ms(void* ev_begin, void* ev_end, float* ms) {
+    QSAE_CHECK_ARG(ev_begin && ev_end && ms, "null pointer");
+    QSAE_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(ev_begin), static_cast<hipEvent_t>(ev_end)));
     return QSAE_OK;
 }
 

@@ -4,8 +4,10 @@ tensors and raises otherwise -- there is no CPU path in this package.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import functools
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -34,32 +36,23 @@ def _on_tensor_device(fn):
 
 
 class _HipEventPair:
-    """Two timing events created through the HIP runtime itself (no dependence on how torch wraps its events): the
-    library records them around its candidate-sweep launch on the launch stream (qsae_profile_sweep_events)."""
-    _hip = None
-
-    @classmethod
-    def hip(cls):
-        if cls._hip is None:
-            cls._hip = C.CDLL("libamdhip64.so")
-            cls._hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
-            cls._hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
-            cls._hip.hipEventDestroy.argtypes = [C.c_void_p]
-        return cls._hip
+    """Two timing events for qsae_profile_sweep_events, created / read / destroyed through libqsae_hip.so itself
+    (qsae_profile_event_*): the runtime that records them is the one that made them."""
 
     def __init__(self):
+        lib = _lib.load()
+        self._lib = lib
         self.a, self.b = C.c_void_p(), C.c_void_p()
         for e in (self.a, self.b):
-            if self.hip().hipEventCreate(C.byref(e)) != 0:
-                raise RuntimeError("hipEventCreate failed")
+            check(lib.qsae_profile_event_create(C.byref(e)))
 
     def elapsed_ms(self):
         ms = C.c_float(0.0)
-        return ms.value if self.hip().hipEventElapsedTime(C.byref(ms), self.a, self.b) == 0 else None
+        return ms.value if self._lib.qsae_profile_event_elapsed_ms(self.a, self.b, C.byref(ms)) == 0 else None
 
     def destroy(self):
         for e in (self.a, self.b):
-            self.hip().hipEventDestroy(e)
+            self._lib.qsae_profile_event_destroy(e)
 
 
 class _KernelTimer:
@@ -217,6 +210,28 @@ def encode_bits_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
 
 
 @_on_tensor_device
+def encode_bits_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                                 meta: torch.Tensor, slot: int = 0) -> "PendingForward":
+    """The two-call form of encode_bits_prefilter (qsae_encode_bits_prefilter_submit / _finish): ``finish()`` returns
+    the z bits; ``flagged_rows`` of the handle is the number of rows that went through the exact dense kernel."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    lib = _lib.load()
+    need = int(lib.qsae_encode_bits_prefilter_workspace_bytes(B, D, H)) if B > 0 else 1
+    if need == 0:
+        raise ValueError("shape not supported by the fp16 candidate sweep")
+    _claim_slot(x.device, slot)
+    ws = _workspace(x.device, need, slot, "pending")
+    words = (H + 31) // 32
+    z = torch.empty((B, words), dtype=torch.int32, device=x.device)
+    cargs = (_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, _p(z), words, _p(ws), ws.numel())
+    return _submit(lib.qsae_encode_bits_prefilter_submit, lib.qsae_encode_bits_prefilter_finish, cargs,
+                   (x, W, b, Wq, meta, ws), z, x.device, slot)
+
+
+@_on_tensor_device
 def topk_rows(latent: torch.Tensor, k: int, zero_rest: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """In-place on `latent` when zero_rest.  Returns (idx int32 [B,k], val f32 [B,k])."""
     _dev(latent, "latent", torch.float32)
@@ -230,26 +245,41 @@ def topk_rows(latent: torch.Tensor, k: int, zero_rest: bool) -> Tuple[torch.Tens
     return idx, val
 
 
-_workspaces = {}
+_workspaces = collections.OrderedDict()     # (device, stream handle, kind, slot) -> uint8 tensor, least recently used first
+#: scratch buffers kept per device (each is ~0.7 GB at the headline shape): the blocking calls of one stream need one,
+#: every batch in flight another; streams / threads that have gone leave theirs behind until they fall off this list
+WORKSPACE_CACHE_PER_DEVICE = 6
+_busy_slots = {}                            # (device, stream handle, slot) -> PendingForward that owns the slot
 
 
-def _workspace(device: torch.device, nbytes: int, slot: int = 0) -> torch.Tensor:
-    """Scratch for one call in flight: one buffer per (device, stream, slot).  Two streams never share one (their
+def _workspace(device: torch.device, nbytes: int, slot: int = 0, kind: str = "call") -> torch.Tensor:
+    """Scratch for one call in flight: one buffer per (device, stream, kind, slot).  Two streams never share one (their
     kernels would write the same candidate lists), and a buffer that has to grow is simply replaced: the old block goes
     back to the caching allocator, which reuses memory in the order of the stream it was allocated on -- the same
-    stream every user of this buffer ran on.  `slot` separates batches that are in flight together on one stream
-    (submit / finish)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream, slot)
+    stream every user of this buffer ran on.  kind "call" = the blocking entry points (whose use of the buffer ends with
+    the call's last kernel), kind "pending" = submit / finish pairs, which own their buffer until finish() -- a blocking
+    call between the two must not touch it -- with ``slot`` separating batches in flight together on one stream.
+    The cache keeps the WORKSPACE_CACHE_PER_DEVICE most recently used buffers of a device (release_workspaces()
+    drops all)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream(device).cuda_stream, kind, slot)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+    _workspaces.move_to_end(key)
+    mine = [k for k in _workspaces if k[0] == dev]
+    for k in mine[:max(0, len(mine) - WORKSPACE_CACHE_PER_DEVICE)]:
+        ref = _busy_slots.get((k[0], k[1], k[3])) if k[2] == "pending" else None
+        if ref is not None and ref() is not None:
+            continue                        # a batch in flight still owns it
+        del _workspaces[k]                  # (the block returns to the caching allocator, stream-ordered)
     return ws
 
 
 def release_workspaces() -> None:
-    """Drop every cached scratch buffer (they are re-created on demand)."""
+    """Drop every cached scratch buffer (they are re-created on demand).  Buffers of batches still in flight stay alive
+    through their PendingForward handles."""
     _workspaces.clear()
 
 
@@ -342,24 +372,33 @@ def encode_topk_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     return idx, val, (dense[:, :H] if dense_out is not None else dense)
 
 
-def _binary_prefilter_args(x, W, bias, Wq, meta, k, packed, n_bits, step, dec_bias, want_dense, slot):
+def _decode_prefilter_args(x, W, bias, Wq, meta, k, decoder, dec_bias, want_dense, slot, kind):
+    """Argument tuple shared by the forward-in-one-call entry points.  ``decoder`` = ("packed", packed uint8 [H, row_bytes],
+    n_bits, step) or ("table", fp32 [H, D], scale)."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
-    _dev(packed, "packed", torch.uint8)
     B, D = x.shape
     H = W.shape[0]
     b = _f32c(bias, "bias") if bias is not None else None
     db = _f32c(dec_bias, "dec_bias") if dec_bias is not None else None
+    if decoder[0] == "packed":
+        dict_t = _dev(decoder[1], "packed", torch.uint8)
+        dargs = (_p(dict_t), int(decoder[2]), float(decoder[3]))
+    else:
+        dict_t = _f32c(decoder[1], "table")
+        if tuple(dict_t.shape) != (H, D):
+            raise ValueError(f"table is {tuple(dict_t.shape)}, expected [{H}, {D}]")
+        dargs = (_p(dict_t), float(decoder[2]))
     need = int(_lib.load().qsae_encode_topk_prefilter_workspace_bytes(B, D, H, k))
     if need == 0:
         raise ValueError("shape not supported by the fp16 prefilter")
-    ws = _workspace(x.device, need, slot)
+    ws = _workspace(x.device, need, slot, kind)
     idx = torch.empty((B, k), dtype=torch.int32, device=x.device)
     val = torch.empty((B, k), dtype=torch.float32, device=x.device)
     dense = torch.empty((B, H), dtype=torch.float32, device=x.device) if want_dense else None
     recon = torch.empty((B, D), dtype=torch.float32, device=x.device)
-    cargs = (_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k, _p(packed), n_bits, float(step), _p(db), _p(idx), _p(val),
-             _p(dense), H, _p(recon), _p(ws), ws.numel())
-    keep = (x, W, b, Wq, meta, packed, db, ws)          # referenced by the pointers above
+    cargs = (_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, k) + dargs + (_p(db), _p(idx), _p(val), _p(dense), H, _p(recon),
+                                                                          _p(ws), ws.numel())
+    keep = (x, W, b, Wq, meta, dict_t, db, ws)          # referenced by the pointers above
     return cargs, keep, (idx, val, dense, recon)
 
 
@@ -370,7 +409,8 @@ def binary_forward_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[to
                              info: Optional[dict] = None):
     """encode_topk_prefilter + decode_binary_sparse in one call (rows are decoded by the refinement kernel as it
     ranks them): (idx, val, dense latent or None, reconstruction), bit-identical to the two separate calls."""
-    cargs, keep, outs = _binary_prefilter_args(x, W, bias, Wq, meta, k, packed, n_bits, step, dec_bias, want_dense, 0)
+    cargs, keep, outs = _decode_prefilter_args(x, W, bias, Wq, meta, k, ("packed", packed, n_bits, step), dec_bias,
+                                               want_dense, 0, "call")
     flagged = C.c_int(0)
     kernel_timer.arm_sweep()
     check(_lib.load().qsae_binary_forward_prefilter(*cargs, int(spec_rows), C.byref(flagged), _stream()))
@@ -379,25 +419,87 @@ def binary_forward_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[to
     return outs
 
 
-class PendingForward:
-    """A batch whose main kernels are queued (binary_forward_prefilter_submit).  ``finish()`` waits for the 4-byte
-    count of rows that need the exact fallback -- by then the GPU is usually busy with the NEXT batch's kernels --
-    enqueues that fallback and returns (idx, val, dense latent or None, reconstruction).  The outputs must not be read
-    before ``finish()`` has returned.  Not safe to share between threads."""
+@_on_tensor_device
+def table_forward_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                            meta: torch.Tensor, k: int, table: torch.Tensor, scale: float,
+                            dec_bias: Optional[torch.Tensor], want_dense: bool = True, spec_rows: int = 0,
+                            info: Optional[dict] = None):
+    """encode_topk_prefilter + decode_table_sparse in one call (fp32 dictionary rows [H, D]: the Baseline decoder, the
+    soft integers of an unpolarised BinarySAE): (idx, val, dense latent or None, reconstruction), bit-identical to the
+    two separate calls."""
+    cargs, keep, outs = _decode_prefilter_args(x, W, bias, Wq, meta, k, ("table", table, scale), dec_bias, want_dense, 0,
+                                               "call")
+    flagged = C.c_int(0)
+    kernel_timer.arm_sweep()
+    check(_lib.load().qsae_table_forward_prefilter(*cargs, int(spec_rows), C.byref(flagged), _stream()))
+    if info is not None:
+        info["flagged_rows"] = int(flagged.value)
+    return outs
 
-    def __init__(self, cargs, keep, outs, word, event, device):
-        self._cargs, self._keep, self._outs, self._word, self._event, self._device = cargs, keep, outs, word, event, device
+
+class PendingForward:
+    """A batch whose main kernels are queued (*_submit).  ``finish()`` waits for the 4-byte count of rows that need
+    the exact fallback -- by then the GPU is usually busy with the NEXT batch's kernels -- enqueues that fallback ON THE
+    STREAM THE BATCH WAS SUBMITTED ON and returns the outputs, which must not be read before ``finish()`` has returned.
+    The handle owns its workspace slot from submit to finish: a second submit into the same slot raises, and the
+    blocking entry points use buffers of their own, so nothing between the two calls can disturb the lists the fallback
+    reads.  Not safe to share between threads."""
+
+    def __init__(self, finish_fn, cargs, keep, outs, word, event, device, stream, slot_key):
+        self._finish_fn, self._cargs, self._keep, self._outs = finish_fn, cargs, keep, outs
+        self._word, self._event, self._device, self._stream, self._slot_key = word, event, device, stream, slot_key
         self.flagged_rows = None
+        _busy_slots[slot_key] = weakref.ref(self)       # (weak: a dropped handle must still be collected)
+
+    def _release(self):
+        ref = _busy_slots.get(self._slot_key)
+        if ref is not None and ref() in (self, None):
+            del _busy_slots[self._slot_key]
+        self._cargs = self._keep = None
 
     def finish(self):
         if self._cargs is None:
             return self._outs
         self._event.synchronize()                      # the count has landed in the pinned word
         self.flagged_rows = int(self._word.item())
-        with torch.cuda.device(self._device):
-            check(_lib.load().qsae_prefilter_finish(*self._cargs, self.flagged_rows, _stream()))
-        self._cargs = self._keep = None
+        try:
+            with torch.cuda.device(self._device), torch.cuda.stream(self._stream):
+                check(self._finish_fn(*self._cargs, self.flagged_rows, _stream()))
+        finally:
+            self._release()
         return self._outs
+
+    def __del__(self):
+        # dropped without finish(): the asynchronous 4-byte copy may still be pending -- the pinned word must outlive it
+        try:
+            if self._cargs is not None:
+                self._event.synchronize()
+                self._release()
+        except Exception:
+            pass
+
+
+def _submit(submit_fn, finish_fn, cargs, keep, outs, device, slot):
+    stream = torch.cuda.current_stream(device)
+    slot_key = (device.index if device.index is not None else torch.cuda.current_device(), stream.cuda_stream, slot)
+    word = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    kernel_timer.arm_sweep()
+    check(submit_fn(*cargs, C.c_void_p(word.data_ptr()), _stream()))
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return PendingForward(finish_fn, cargs, keep, outs, word, ev, device, stream, slot_key)
+
+
+def _claim_slot(device, slot):
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream, slot)
+    ref = _busy_slots.get(key)
+    if ref is not None and ref() is None:
+        del _busy_slots[key]                # its handle is gone (collected without finish)
+        ref = None
+    if ref is not None:
+        raise RuntimeError(f"submit: slot {slot} of this stream still holds a batch whose finish() / result() has not been "
+                           "called; batches in flight together need different slot numbers")
 
 
 @_on_tensor_device
@@ -408,13 +510,24 @@ def binary_forward_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Opti
     """The two-call form of binary_forward_prefilter (qsae_prefilter_submit / _finish): nothing in here waits for the
     GPU, so the caller can submit batch i+1 before it finishes batch i.  Batches in flight together on one stream
     need different ``slot`` numbers (each slot is a workspace of its own); finish them in submission order."""
-    cargs, keep, outs = _binary_prefilter_args(x, W, bias, Wq, meta, k, packed, n_bits, step, dec_bias, want_dense, slot)
-    word = torch.zeros((1,), dtype=torch.int32).pin_memory()
-    kernel_timer.arm_sweep()
-    check(_lib.load().qsae_prefilter_submit(*cargs, C.c_void_p(word.data_ptr()), _stream()))
-    ev = torch.cuda.Event()
-    ev.record()
-    return PendingForward(cargs, keep, outs, word, ev, x.device)
+    _claim_slot(x.device, slot)
+    cargs, keep, outs = _decode_prefilter_args(x, W, bias, Wq, meta, k, ("packed", packed, n_bits, step), dec_bias,
+                                               want_dense, slot, "pending")
+    lib = _lib.load()
+    return _submit(lib.qsae_prefilter_submit, lib.qsae_prefilter_finish, cargs, keep, outs, x.device, slot)
+
+
+@_on_tensor_device
+def table_forward_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                                   meta: torch.Tensor, k: int, table: torch.Tensor, scale: float,
+                                   dec_bias: Optional[torch.Tensor], want_dense: bool = True,
+                                   slot: int = 0) -> PendingForward:
+    """The two-call form of table_forward_prefilter (qsae_prefilter_submit_table / _finish_table)."""
+    _claim_slot(x.device, slot)
+    cargs, keep, outs = _decode_prefilter_args(x, W, bias, Wq, meta, k, ("table", table, scale), dec_bias, want_dense, slot,
+                                               "pending")
+    lib = _lib.load()
+    return _submit(lib.qsae_prefilter_submit_table, lib.qsae_prefilter_finish_table, cargs, keep, outs, x.device, slot)
 
 
 @_on_tensor_device

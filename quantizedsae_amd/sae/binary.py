@@ -24,16 +24,22 @@ class binary_decoder(nn.Module):
         soft_gap = max over (h, d) of |soft integer - hard integer|        (qsae_pack_binary)
 
     ``decode_mode``:
-      * ``"auto"`` (default) -- hard packed decode when ``soft_gap <= hard_max_gap`` (1e-6: logits beyond
-        about +-17, reconstructions equal to the reference's to ~1e-6 relative), otherwise the reference's soft
+      * ``"auto"`` (default) -- hard packed decode when ``soft_gap <= hard_max_gap * (2^n_bits - 1)`` (1e-7 of the
+        integer range: every logit beyond about +-16.2, whatever n_bits; reconstructions then equal the reference's to
+        ~1e-6 relative), otherwise the reference's soft
         arithmetic over an fp32 ``[H, D]`` table (a warning says so once per checkpoint);
       * ``"hard"`` -- always the packed integers (the deployment form; differs from the reference forward
         on an unpolarised checkpoint by up to tens of percent, see scripts/evaluation/estimate_quantization_error.py);
       * ``"soft"`` -- always the soft table.
     """
 
-    #: auto mode: largest |soft - hard| (in integer steps) for which the hard decode stands in for the soft one
-    hard_max_gap = 1e-6
+    #: auto mode: largest |soft - hard|, as a fraction of the integer range 2^n_bits - 1 (a per-bit saturation measure:
+    #: the gap of a dictionary whose logits all sit at +-L is (2^n_bits - 1) sigmoid(-L)), for which the hard decode
+    #: stands in for the soft one
+    hard_max_gap = 1e-7
+
+    def hard_gap_limit(self) -> float:
+        return self.hard_max_gap * float(2 ** self.n_bits - 1)
 
     def __init__(self, in_features, out_features, gamma=4.0, n_bits=8):
         super().__init__()
@@ -79,13 +85,13 @@ class binary_decoder(nn.Module):
         if mode != "auto":
             raise ValueError(f"decode_mode must be 'auto', 'hard' or 'soft', got {mode!r}")
         st = self.packed()
-        if st["soft_gap"] <= self.hard_max_gap:
+        if st["soft_gap"] <= self.hard_gap_limit():
             return "hard"
         if not st.get("warned"):
             st["warned"] = True
             warnings.warn(
                 f"binary_decoder: checkpoint is not polarised (max |soft - hard| integer gap {st['soft_gap']:.3g} > "
-                f"{self.hard_max_gap:g}); decoding with the reference's soft sigmoid-bit table (sae/binary.py:26-38). "
+                f"{self.hard_gap_limit():g}); decoding with the reference's soft sigmoid-bit table (sae/binary.py:26-38). "
                 "Set decode_mode='hard' for the packed two's-complement dictionary.", stacklevel=3)
         return "soft"
 
@@ -221,11 +227,18 @@ class BinarySAE(SparseAutoencoder):
             xf = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
             spec = 32 if self.last_flagged_rows > 0 else 0
             info = {}
-            if hard and self.fuse_decode:
+            if self.fuse_decode:
+                # one call: the refinement kernel decodes every row it ranks -- from the packed n-bit dictionary, or from
+                # the fp32 soft-integer table when the checkpoint is not polarised (the reference's own arithmetic)
                 dec = self.decoder
-                idx, val, latent, recon = ops.binary_forward_prefilter(
-                    xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.packed()["packed"],
-                    dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=want_dense, spec_rows=spec, info=info)
+                if hard:
+                    idx, val, latent, recon = ops.binary_forward_prefilter(
+                        xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.packed()["packed"],
+                        dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=want_dense, spec_rows=spec, info=info)
+                else:
+                    idx, val, latent, recon = ops.table_forward_prefilter(
+                        xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.soft_table(),
+                        dec.quantization_step, dec.bias.detach(), want_dense=want_dense, spec_rows=spec, info=info)
                 self.last_flagged_rows = info["flagged_rows"]
                 return idx, val, latent, recon
             idx, val, latent = ops.encode_topk_prefilter(xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"],
@@ -258,20 +271,25 @@ class BinarySAE(SparseAutoencoder):
     def forward_submit(self, x, slot: int = 0, want_dense: bool = True):
         """Queue one forward without waiting for the GPU anywhere: returns a handle whose ``result()`` gives
         ``(latent, reconstruction, polarize_loss)`` (``(idx, val, reconstruction)`` with want_dense=False).  With the
-        default path this is the two-call form of the C ABI (qsae_prefilter_submit / _finish): submit batch i+1, then
+        default path this is the two-call form of the C ABI (qsae_prefilter_submit / _finish, or their _table forms for
+        an unpolarised checkpoint): submit batch i+1, then
         call ``result()`` of batch i -- the 4-byte read-back of batch i no longer idles the GPU.  Batches in flight
         together need different ``slot`` numbers; other paths compute eagerly and return a finished handle."""
         with torch.no_grad():
             xd = require_device_input(x, "x")
-            if (self.top_k > 0 and self.resolved_latent_path(xd.shape[0]) == "prefilter" and self.fuse_decode
-                    and self.decoder.resolved_decode_mode() == "hard"):
+            if self.top_k > 0 and self.resolved_latent_path(xd.shape[0]) == "prefilter" and self.fuse_decode:
                 self._check_limits("prefilter")
                 lin, dec = self.encoder.linear, self.decoder
                 pw = self._prefilter_weights()
                 xf = xd if (xd.dtype == torch.float32 and xd.is_contiguous()) else xd.float().contiguous()
-                pending = ops.binary_forward_prefilter_submit(
-                    xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.packed()["packed"],
-                    dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot)
+                if dec.resolved_decode_mode() == "hard":
+                    pending = ops.binary_forward_prefilter_submit(
+                        xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.packed()["packed"],
+                        dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot)
+                else:
+                    pending = ops.table_forward_prefilter_submit(
+                        xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.soft_table(),
+                        dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot)
                 return _SubmittedForward(self, pending, None, want_dense)
             return _SubmittedForward(self, None, self._run(xd, want_dense), want_dense)
 

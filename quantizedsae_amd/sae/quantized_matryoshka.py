@@ -110,13 +110,16 @@ class QuantizedMatryoshkaDecoder(nn.Module):
     SPARSE_MAX_ACTIVE_FRACTION = 0.12
 
     def active_fraction_hint(self):
-        """Fraction of active units in the previous decode call (None before the first one).  The counts of that
-        call are read here, one call later, when they have long been computed."""
+        """Fraction of active units in the most recent decode call whose counts have reached the host (None before the
+        first one).  The counts travel to a page-locked buffer behind the decode (asynchronous copy + event) and are
+        taken from there once the event has completed -- nothing here waits for the GPU, so a forward queued behind
+        another one is not held up by the hint; at worst the hint is one batch older."""
         pending = getattr(self, "_pending_counts", None)
         if pending is not None:
-            counts, rows, units = pending
-            self._active_fraction = float(counts.sum().item()) / max(rows * units, 1)
-            self._pending_counts = None
+            host, event, rows, units = pending
+            if event.query():
+                self._active_fraction = float(host.sum()) / max(rows * units, 1)
+                self._pending_counts = None
         return getattr(self, "_active_fraction", None)
 
     def decode_bits(self, zbits: torch.Tensor, sparse=None) -> Tuple[list, list]:
@@ -136,7 +139,11 @@ class QuantizedMatryoshkaDecoder(nn.Module):
         else:
             levels, counts = ops.decode_matryoshka(zbits, st["H"], self.out_features, self.n_bits, st["codes"],
                                                    st["scale"], self.bias.detach(), self.allow_bias, st["sizes"])
-        self._pending_counts = (counts, B, st["H"])
+        host = torch.empty((self.n_bits,), dtype=torch.int64).pin_memory()
+        host.copy_(counts, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._pending_counts = (host, event, B, st["H"])
         groups = (counts.to(torch.float64) / max(B, 1)).to(torch.float32)
         return [groups[i] for i in range(self.n_bits)], [levels[i] for i in range(self.n_bits)]
 
@@ -251,3 +258,35 @@ class QuantizedMatryoshkaSAE(SparseAutoencoder):
             # few flagged rows = few active units: walk them; otherwise the decoder decides from the last batch's density
             sparse = True if (path == "prefilter" and self.last_flagged_rows * 8 <= x.shape[0]) else None
             return self.decoder.decode_bits(z, sparse=sparse)
+
+    def forward_submit(self, x, slot: int = 0):
+        """Queue one forward without waiting for the GPU (see BinarySAE.forward_submit): the z bits of the fp16 candidate
+        sweep are queued here (qsae_encode_bits_prefilter_submit); ``result()`` takes the count of rows that need the
+        exact dense kernel, queues those and the decoder, and returns ``(latent_groups, reconstruction_levels)``.
+        Batches in flight together need different ``slot`` numbers; models on the dense path compute eagerly."""
+        with torch.no_grad():
+            xd = require_device_input(x, "x")
+            if self.resolved_bits_path(xd.shape[0]) != "prefilter":
+                return _SubmittedMatryoshka(self, None, self.forward(xd), xd.shape[0])
+            W, b = self._encoder_params()
+            pw = self._prefilter_weights()
+            pending = ops.encode_bits_prefilter_submit(xd.float(), W, b, pw["Wq"], pw["meta"], slot=slot)
+            return _SubmittedMatryoshka(self, pending, None, xd.shape[0])
+
+
+class _SubmittedMatryoshka:
+    def __init__(self, model, pending, outs, rows):
+        self._model, self._pending, self._outs, self._rows = model, pending, outs, rows
+
+    def result(self):
+        with torch.no_grad():
+            if self._pending is not None:
+                m = self._model
+                z = self._pending.finish()
+                flagged = m.last_flagged_rows = self._pending.flagged_rows
+                self._pending = None
+                if flagged * 2 > self._rows:
+                    m._dense_regime = True
+                m.decoder.active_fraction_hint()
+                self._outs = m.decoder.decode_bits(z, sparse=True if flagged * 8 <= self._rows else None)
+            return self._outs

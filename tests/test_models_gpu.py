@@ -138,6 +138,28 @@ def test_binary_auto_mode_takes_the_packed_decode_on_polarised_checkpoints():
     assert 1e-5 < model.decoder.packed()["soft_gap"] < 1e-3 and model.decoder.resolved_decode_mode() == "soft"
 
 
+def test_binary_auto_mode_measures_saturation_per_bit_not_per_integer():
+    """The soft / hard gap grows with the integer range: an 8-bit dictionary at +-18 has gap 255 sigmoid(-18) = 3.9e-6 --
+    above an absolute 1e-6, yet every bit is as saturated as a 4-bit dictionary's at the same logits (gap 2.3e-7).  The
+    auto rule compares gap / (2^n_bits - 1) with hard_max_gap, so both take the packed decode; +-12 takes neither."""
+    import warnings
+    for n_bits in (4, 8):
+        m = BinarySAE(64, 1024, gamma=4.0, n_bits=n_bits).to(DEV).eval()
+        g = torch.Generator(device="cpu").manual_seed(n_bits)
+        bits = (torch.rand(m.decoder.weight.shape, generator=g) > 0.5).to(DEV)
+        with torch.no_grad():
+            m.decoder.weight.copy_(torch.where(bits, 18.0, -18.0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            assert m.decoder.resolved_decode_mode() == "hard"
+        gap = m.decoder.packed()["soft_gap"]
+        assert gap == pytest.approx((2 ** n_bits - 1) * 1.523e-8, rel=0.3) and gap <= m.decoder.hard_gap_limit()
+        with torch.no_grad():
+            m.decoder.weight.mul_(12.0 / 18.0)
+        with pytest.warns(UserWarning, match="not polarised"):
+            assert m.decoder.resolved_decode_mode() == "soft"
+
+
 def test_binary_k_zero_and_limits():
     """hidden_dim < 500 -> k = int(H * 0.002) = 0: the reference's topk(0) keeps nothing (zero latent, bias-only
     reconstruction, sae/binary.py:94-99); limits of the kernels are reported as ValueError, not as a HIP error."""

@@ -42,15 +42,17 @@ def test_bench_two_ranks_on_one_card_reduce_the_right_mse():
     assert doc["config"]["rows_per_gpu"] == rows and doc["config"]["latent_path"] == "prefilter"
     assert doc["value"] == pytest.approx(2 * rows * steps / (doc["ms_per_step"] * steps * 1e-3), rel=1e-9)
     assert doc["cpu_baseline"] is None and doc["roofline"]["avg_kernel_ms"] > 0
-    # the same shards, here: rank r draws its rows from torch.Generator(seed 1000 + r) (bench.py)
+    assert doc["input_batches"] == 4 and doc["forward_blocking"]["recon_mse"] == pytest.approx(doc["recon_mse"], rel=1e-12)
+    # the same shards, here: rank r draws its batches from torch.Generator(seed 1000 + r), step i takes batch i mod 4 (bench.py)
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
     sq = torch.zeros((), dtype=torch.float64, device=dev)
     for rank in range(2):
         g = torch.Generator(device=dev)
         g.manual_seed(1000 + rank)
-        x = torch.randn((rows, bench.D), device=dev, generator=g)
-        _lat, rec, _ = model(x)
-        ops.sq_err_sum(rec, x, sq)
-    want = float(sq) / (2 * rows * bench.D)
+        for _ in range(steps):
+            x = torch.randn((rows, bench.D), device=dev, generator=g)
+            _lat, rec, _ = model(x)
+            ops.sq_err_sum(rec, x, sq)
+    want = float(sq) / (2 * steps * rows * bench.D)
     assert doc["recon_mse"] == pytest.approx(want, rel=1e-9)
