@@ -15,7 +15,7 @@ from typing import Iterator, Optional, Tuple
 import torch
 from torch.utils.data import Dataset
 
-from . import ops
+from . import torch_ops as ops
 from .sharding import shard_rows
 
 

@@ -13,7 +13,7 @@ from typing import Any, Dict, Iterable, List, Optional
 
 import torch
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from ..sae import (BaselineSparseAutoencoder, BinarySAE, QuantizedMatryoshkaSAE, ResidualQuantizedSAE)
 from .framework import SAEWrapper, _ensure_tensor, compute_reconstruction_error  # noqa: F401  (re-export)
 

@@ -17,7 +17,7 @@ from typing import Any, Callable, Dict, Iterable, Iterator, Optional, Union
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from ..sae import (
     BaselineSparseAutoencoder,
     BinarySAE,

@@ -6,7 +6,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 
 
 class HipEncoder(nn.Sequential):

@@ -4,11 +4,11 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from .base import HipEncoder, PackedCache, require_device_input
 
 
-class BaselineSparseAutoencoder(nn.Module):
+class BaselineSparseAutoencoder(ops.GraphForwardMixin, nn.Module):
     def __init__(self, input_dim, hidden_dim):
         super().__init__()
         self.encoder = HipEncoder(nn.Linear(input_dim, hidden_dim))   # no ReLU in the reference either
@@ -18,6 +18,7 @@ class BaselineSparseAutoencoder(nn.Module):
         self._cache = PackedCache()
         self._pref_cache = PackedCache()
         self.last_flagged_rows = 0     # rows of the previous prefilter batch that took the exact fallback (per model)
+        ops.module_handle(self)
 
     def _table(self) -> torch.Tensor:
         # decoder.weight is [D, H]; the sparse decode gathers rows of its transpose [H, D]
@@ -69,6 +70,11 @@ class BaselineSparseAutoencoder(nn.Module):
     def forward(self, x):
         """-> (h_sparse [B,H], recon [B,D])  (sae/baseline.py:17-31)."""
         with torch.no_grad():
+            if torch.compiler.is_compiling():          # one graph node: torch.ops.qsae.baseline_sae_forward
+                lin = self.encoder.linear
+                _, _, h, recon = torch.ops.qsae.baseline_sae_forward(
+                    x, [lin.weight, lin.bias, self.decoder.weight, self.decoder.bias], self._qsae_handle, True)
+                return h, recon
             _, _, h, recon = self._run(x, want_dense=True)
             return h, recon
 

@@ -7,7 +7,7 @@ import warnings
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from .base import HipEncoder, PackedCache, SparseAutoencoder, require_device_input
 
 
@@ -128,7 +128,7 @@ class binary_decoder(nn.Module):
             return ops.binary_soft_table(self.weight.detach(), self.out_features, self.n_bits)
 
 
-class BinarySAE(SparseAutoencoder):
+class BinarySAE(ops.GraphForwardMixin, SparseAutoencoder):
     """``forward(x) -> (sparse_latent [B,H], reconstruction [B,D], polarize_loss [])``
     (sae/binary.py:71-103).  k = int(hidden_dim * self.k) with self.k = 0.002.
 
@@ -151,6 +151,7 @@ class BinarySAE(SparseAutoencoder):
         #: rows of the previous prefilter batch that went through the exact fallback kernels (sizes the next call's
         #: speculative fallback; per model, not per process)
         self.last_flagged_rows = 0
+        ops.module_handle(self)
 
     @property
     def top_k(self) -> int:
@@ -255,15 +256,25 @@ class BinarySAE(SparseAutoencoder):
             idx, val = ops.topk_rows(latent, self.top_k, zero_rest=True)     # latent * mask, in place
         return idx, val, latent, self.decoder.decode_sparse(idx, val)
 
+    def _graph_params(self):
+        lin, dec = self.encoder.linear, self.decoder
+        return [lin.weight, lin.bias, dec.weight, dec.bias]
+
     def forward_compact(self, x):
         """(idx int32 [B,k], val fp32 [B,k], reconstruction [B,D]) without the dense latent; same path
         selection (and the same bits) as forward()."""
         with torch.no_grad():
+            if torch.compiler.is_compiling():          # one graph node: torch.ops.qsae.binary_sae_forward
+                idx, val, _, recon, _ = torch.ops.qsae.binary_sae_forward(x, self._graph_params(), self._qsae_handle, False)
+                return idx, val, recon
             idx, val, _, recon = self._run(x, want_dense=False)
             return idx, val, recon
 
     def forward(self, x):
         with torch.no_grad():
+            if torch.compiler.is_compiling():          # one graph node: torch.ops.qsae.binary_sae_forward
+                _, _, latent, recon, pol = torch.ops.qsae.binary_sae_forward(x, self._graph_params(), self._qsae_handle, True)
+                return latent, recon, pol
             _, _, latent, recon = self._run(x, want_dense=True)
             return latent, recon, self.decoder.packed()["polarize"]
 

@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from .base import HipEncoder, SparseAutoencoder, require_device_input
 
 # sigmoid(w) >= 0.5 in the reference's fp32 op sequence  <=>  w >= this pre-activation (bit pattern 0xB43FFFFE,

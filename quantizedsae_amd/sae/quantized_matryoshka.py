@@ -7,7 +7,7 @@ from typing import List, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from .base import HipEncoder, PackedCache, SparseAutoencoder, require_device_input
 
 _TRAINING_ONLY = ("the secant-gradient correction belongs to the reference's training loop "
@@ -164,7 +164,7 @@ class QuantizedMatryoshkaDecoder(nn.Module):
         raise NotImplementedError(_TRAINING_ONLY)
 
 
-class QuantizedMatryoshkaSAE(SparseAutoencoder):
+class QuantizedMatryoshkaSAE(ops.GraphForwardMixin, SparseAutoencoder):
     """``forward(x) -> (latent_groups, reconstruction_levels)``; ``top_k`` is stored and unused, as
     in the reference (sae/quantized_matryoshka.py:192-220)."""
 
@@ -183,6 +183,7 @@ class QuantizedMatryoshkaSAE(SparseAutoencoder):
         self.decoder = QuantizedMatryoshkaDecoder(hidden_dim, input_dim, abs_range=abs_range, n_bits=n_bits,
                                                   top_k=self.top_k, allow_bias=self.allow_bias)
         self._enc_cache = PackedCache()
+        ops.module_handle(self)
 
     def _encoder_params(self):
         """Encoder weight/bias in the decoder's packed hidden order (inert pad units get a zero row
@@ -250,6 +251,15 @@ class QuantizedMatryoshkaSAE(SparseAutoencoder):
             return ops.encode_bits(x, W, b)
 
     def forward(self, x):
+        if torch.compiler.is_compiling():                  # one graph node: torch.ops.qsae.levels_sae_forward
+            lin, dec = self.encoder.linear, self.decoder
+            with torch.no_grad():
+                groups, levels = torch.ops.qsae.levels_sae_forward(
+                    x, [lin.weight, lin.bias, dec.weight, dec.weight_mirror, dec.bias], self._qsae_handle)
+            return [groups[i] for i in range(self.n_bits)], [levels[i] for i in range(self.n_bits)]
+        return self._forward_eager(x)
+
+    def _forward_eager(self, x):
         with torch.no_grad():
             x = require_device_input(x, "x")
             self.decoder.active_fraction_hint()            # reads the previous call's counts before anything is queued

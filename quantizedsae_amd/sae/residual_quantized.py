@@ -5,12 +5,12 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from .base import SparseAutoencoder, require_device_input
 from .quantized_matryoshka import QuantizedMatryoshkaSAE, nested_sizes
 
 
-class ResidualQuantizedSAE(SparseAutoencoder):
+class ResidualQuantizedSAE(ops.GraphForwardMixin, SparseAutoencoder):
     """``forward(x) -> (latent_groups, reconstruction_levels)``: stage i encodes the residual left
     by stage i-1, ``residual = (residual - recon) * 2``; only stage 0 has a decoder bias."""
 
@@ -27,8 +27,16 @@ class ResidualQuantizedSAE(SparseAutoencoder):
                                    allow_bias=(i == 0))
             for i, h in enumerate(self.sae_hidden_dims)
         ])
+        ops.module_handle(self)
 
     def forward(self, x):
+        if torch.compiler.is_compiling():                  # one graph node: torch.ops.qsae.levels_sae_forward
+            with torch.no_grad():
+                groups, levels = torch.ops.qsae.levels_sae_forward(x, [p for p in self.parameters()], self._qsae_handle)
+            return [groups[i] for i in range(self.n_bits)], [levels[i] for i in range(self.n_bits)]
+        return self._forward_eager(x)
+
+    def _forward_eager(self, x):
         with torch.no_grad():
             residual = require_device_input(x, "x")
             if residual.dtype != torch.float32:

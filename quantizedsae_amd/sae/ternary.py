@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import torch_ops as ops          # torch.ops.qsae.* (dispatcher ops over the C ABI)
 from .base import HipEncoder, PackedCache, require_device_input
 
 _TRAINING_ONLY = ("RigL mask maintenance is part of the reference's training loop "
@@ -54,7 +54,7 @@ class STEWeights(nn.Module):
         raise NotImplementedError(_TRAINING_ONLY)
 
 
-class TernarySparseAutoencoder(nn.Module):
+class TernarySparseAutoencoder(ops.GraphForwardMixin, nn.Module):
     """``forward(x) -> (h [B,H], recon [B,D])``; no top-k in forward (sae/ternary.py:116-122)."""
 
     def __init__(self, input_dim, hidden_dim):
@@ -62,6 +62,7 @@ class TernarySparseAutoencoder(nn.Module):
         self.encoder = HipEncoder(nn.Linear(input_dim, hidden_dim), nn.ReLU())
         self.decoder = STEWeights(hidden_dim, input_dim)
         self.topk = int(hidden_dim * 0.002)
+        ops.module_handle(self)
 
     def apply_topk_activation(self, h):
         """Top-k of each row with non-positive survivors zeroed (sae/ternary.py:102-114)."""
@@ -70,6 +71,13 @@ class TernarySparseAutoencoder(nn.Module):
             ops.topk_rows(out, self.topk, zero_rest=True)
             return torch.clamp_(out, min=0)
 
-    def forward(self, x):
+    def _forward_eager(self, x):
         h = self.encoder(require_device_input(x, "x"))
         return h, self.decoder(h)
+
+    def forward(self, x):
+        if torch.compiler.is_compiling():              # one graph node: torch.ops.qsae.ternary_sae_forward
+            with torch.no_grad():
+                lin = self.encoder.linear
+                return torch.ops.qsae.ternary_sae_forward(x, [lin.weight, lin.bias, self.decoder.weight], self._qsae_handle)
+        return self._forward_eager(x)

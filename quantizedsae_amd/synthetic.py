@@ -132,3 +132,32 @@ def matryoshka_sae_params(seed: int, D: int, H: int, enc_bias_shift: float = Non
 
 def activations(seed: int, B: int, D: int, stream: int = 9) -> np.ndarray:
     return normal(seed, (B, D), stream=stream)
+
+
+# ---------------------------------------------------------------------------
+# Config 5 stand-ins (BASELINE.json: "pythia-70m-deduped activation stream"; the real dumps do not exist offline)
+
+HEAVY_DIMS = (7, 100, 300, 511)        # residual-stream "massive activation" dimensions of the heavy-tailed stand-in
+
+
+def heavy_tailed_activations(seed: int, B: int, D: int, stream: int = 9, dim_scale: float = 30.0,
+                             row_spread: float = 10.0) -> np.ndarray:
+    """Bell-shaped rows with (i) four dimensions at dim_scale times the scale of the rest -- the few outlier
+    dimensions transformer residual streams carry -- and (ii) a per-row scale spread over a factor row_spread
+    (log-uniform): rows of very different norm in one batch.  What this stresses: the prefilter's error budget
+    eps_b grows with ||x_b|| max||W_h||, so outlier dimensions and heavy encoder rows widen every unit's margin."""
+    x = normal(seed, (B, D), stream=stream)
+    for d in HEAVY_DIMS:
+        if d < D:
+            x[:, d] *= np.float32(dim_scale)
+    u = uniform01(seed, B, stream=stream * 16 + 15)
+    x *= np.exp((u - 0.5) * np.log(row_spread)).astype(np.float32)[:, None]
+    return x
+
+
+def heavy_tailed_binary_sae_params(seed: int, D: int, H: int, n_bits: int, logit_mag: float = 30.0) -> dict:
+    """binary_sae_params with encoder biases != 0 (bell, std 0.1) and 1 % of the encoder rows at 5 times their norm."""
+    sd = binary_sae_params(seed, D, H, n_bits, logit_mag, enc_bias_std=0.1, dec_bias_std=0.05)
+    heavy = hash_u64(seed, H, stream=77) % np.uint64(100) == 0
+    sd["encoder.0.weight"][heavy] *= np.float32(5.0)
+    return sd

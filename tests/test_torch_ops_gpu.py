@@ -1,0 +1,96 @@
+"""torch.ops.qsae.* on the GPU: the dispatcher ops return the bits of the ctypes front-end, pass torch.library.opcheck
+(schema, fake tensors, functionalisation), and torch.compile(model, fullgraph=True) returns the bits of the eager forward for
+every module class and for SAEWrapper.__call__ (reference call site: inference/framework.py:316-319)."""
+import numpy as np
+import pytest
+import torch
+
+from quantizedsae_amd import (BaselineSparseAutoencoder, BinarySAE, QuantizedMatryoshkaSAE, ResidualQuantizedSAE,
+                              TernarySparseAutoencoder, ops, synthetic as S)
+from quantizedsae_amd.inference.framework import SAE_REGISTRY, SAEWrapper
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def same_bits(a, b):
+    flat = lambda o: [t for t in (o if isinstance(o, (list, tuple)) else [o]) for t in (t if isinstance(t, (list, tuple)) else [t])]
+    fa, fb = flat(a), flat(b)
+    return len(fa) == len(fb) and all(torch.equal(u.contiguous().view(torch.int32), v.contiguous().view(torch.int32))
+                                      for u, v in zip(fa, fb))
+
+
+def binary_model(H=8192, D=512, n_bits=4):
+    sd = S.binary_sae_params(91, D, H, n_bits, 30.0, 0.05, 0.1)
+    m = BinarySAE(D, H, gamma=4.0, n_bits=n_bits)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(DEV).eval()
+
+
+def test_kernel_level_ops_equal_the_ctypes_front_end_and_pass_opcheck():
+    m = binary_model()
+    lin, dec = m.encoder.linear, m.decoder
+    B = 4096
+    x = torch.from_numpy(S.activations(92, B, 512)).to(DEV)
+    W, b = lin.weight.detach(), lin.bias.detach()
+    Wq, meta = torch.ops.qsae.prefilter_pack_w(W, b)
+    Wq0, meta0 = ops.prefilter_pack_w(W, b)
+    assert torch.equal(Wq, Wq0) and torch.equal(meta, meta0)
+    packed, pol, gap = torch.ops.qsae.pack_binary(dec.weight.detach(), 512, 4)
+    assert torch.equal(packed, ops.pack_binary(dec.weight.detach(), 512, 4)[0])
+    got = torch.ops.qsae.binary_forward_prefilter(x, W, b, Wq, meta, m.top_k, packed, 4, 0.5, dec.bias.detach(), True, 0)
+    want = ops.binary_forward_prefilter(x, W, b, Wq, meta, m.top_k, packed, 4, 0.5, dec.bias.detach())
+    assert same_bits(got[:4], want) and int(got[4]) == 0
+    lat = torch.ops.qsae.encode_dense(x[:256], W, b, ops.ACT_NONE, False)
+    assert same_bits(lat, ops.encode_dense(x[:256], W, b))
+    l2 = lat.clone()
+    idx, val = torch.ops.qsae.topk_rows(l2, m.top_k, True)
+    assert int((l2 != 0).sum()) == 256 * m.top_k and same_bits(torch.gather(lat, 1, idx.long()), val)
+    xs = x[:64].contiguous()
+    torch.library.opcheck(torch.ops.qsae.encode_dense.default, (xs, W, b, ops.ACT_RELU, False))
+    torch.library.opcheck(torch.ops.qsae.topk_rows.default, (lat[:64].clone(), m.top_k, True))
+    torch.library.opcheck(torch.ops.qsae.decode_binary_sparse.default, (idx[:64].contiguous(), val[:64].contiguous(), packed, 512, 4, 0.5, None))
+    torch.library.opcheck(torch.ops.qsae.binary_forward_prefilter.default,
+                          (x, W, b, Wq, meta, m.top_k, packed, 4, 0.5, dec.bias.detach(), False, 0))
+    acc = torch.zeros((), dtype=torch.float64, device=DEV)
+    torch.library.opcheck(torch.ops.qsae.sq_err_sum.default, (got[3], x, acc))
+
+
+def _models():
+    tern = TernarySparseAutoencoder(512, 4096)
+    with torch.no_grad():
+        tern.decoder.weight.normal_(0, 0.5)
+    mat = QuantizedMatryoshkaSAE(512, 8192, top_k=32, abs_range=4, n_bits=4)
+    with torch.no_grad():
+        mat.encoder[0].bias.fill_(-0.8)
+    return [binary_model(), BaselineSparseAutoencoder(512, 8192), tern, mat,
+            ResidualQuantizedSAE(512, 4096, top_k=32, abs_range=1.5, n_bits=4)]
+
+
+@pytest.mark.parametrize("rows", [4096, 100])            # candidate-sweep paths and the small-batch paths
+def test_compiled_forward_returns_the_eager_bits(rows):
+    x = torch.from_numpy(S.activations(93, rows, 512)).to(DEV)
+    for model in _models():
+        model = model.to(DEV).eval()
+        want = model(x)
+        compiled = torch.compile(model, fullgraph=True, backend="aot_eager")
+        got = compiled(x)
+        assert same_bits(got, want), type(model).__name__
+        got2 = compiled(torch.roll(x, 3, 0))              # second call: no retrace needed, same module behind the node
+        assert same_bits(got2, model(torch.roll(x, 3, 0))), type(model).__name__
+
+
+def test_compiled_wrapper_call_and_weight_edits():
+    """SAEWrapper.__call__ under torch.compile; an in-place weight edit after compilation is seen (the node finds the
+    module, whose derived-weight caches are keyed on parameter versions)."""
+    model = binary_model()
+    sae = SAEWrapper(SAE_REGISTRY["b_sae"], model, DEV)
+    x = torch.from_numpy(S.activations(94, 4096, 512)).to(DEV)
+    call = torch.compile(lambda t: sae(t), fullgraph=True, backend="aot_eager")
+    out, want = call(x), sae(x)
+    assert same_bits([out["latent"], out["reconstruction"]], [want["latent"], want["reconstruction"]])
+    with torch.no_grad():
+        model.decoder.bias.add_(1.0)
+    out2, want2 = call(x), sae(x)
+    assert same_bits(out2["reconstruction"], want2["reconstruction"])
+    assert not torch.equal(out2["reconstruction"], out["reconstruction"])
