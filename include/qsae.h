@@ -311,6 +311,30 @@ int qsae_decode_matryoshka_sparse(const uint32_t* zbits, int64_t words_ld, int B
 int qsae_pack_bits_gt(const float* dense, int64_t ld, int B, int H, float thr, uint32_t* zbits,
                       int64_t words_ld, qsae_stream_t stream);
 
+/* -- the dense decoders on the bf16 matrix pipe ------------------------------------------------------ */
+/* qsae_decode_ternary_dense and qsae_decode_matryoshka contract a dictionary of {-1, 0, +1} with fp32 MFMA, at 1/16 of the
+ * bf16 rate.  The *_split forms give the same sums from v_mfma_f32_32x32x16_bf16: the fp32 operand (the latent h, resp.
+ * z_j * 2 scale_j) is split exactly into three bf16 terms (8 + 8 + 8 mantissa bits), the dictionary entries are exact in
+ * bf16, so every product is exact and the three passes add into one fp32 accumulator.  What differs from the fp32 kernels
+ * is the order of the fp32 accumulation roundings (results agree to ~1e-6 relative; both are graded at 1e-5 against the
+ * fp64-accumulating oracle).  D == 512, H % 64 == 0 (matryoshka: level boundaries % 64 == 0); qsae_split_dec_supported() says
+ * whether a shape qualifies.
+ *   qsae_expand_codes_bf16: once per checkpoint, codes2 [D][ceil(H/16)] (as produced by qsae_pack_ternary or
+ *     qsae_pack_matryoshka) -> the bf16 image the kernels stream (qsae_expand_codes_bf16_bytes() = 2 H D bytes, opaque);
+ *   qsae_split_scale_bf16: once per checkpoint, scale [H] (qsae_pack_matryoshka) -> the three bf16 terms of 2 scale,
+ *     s3 [3][H] bf16 (6 H bytes). */
+int qsae_split_dec_supported(int B, int H, int D);
+size_t qsae_expand_codes_bf16_bytes(int D, int H);
+int qsae_expand_codes_bf16(const uint32_t* codes2, int D, int H, void* tq, qsae_stream_t stream);
+/* recon[b][d] = sum_h h[b][h] * hard[d][h] (sae/ternary.py:41-52), h [B][ld] fp32. */
+int qsae_decode_ternary_dense_split(const float* h, int64_t ld, int B, int H, const void* tq, int D, float* recon,
+                                    qsae_stream_t stream);
+int qsae_split_scale_bf16(const float* scale, int H, void* s3, qsae_stream_t stream);
+/* levels / l0_counts as qsae_decode_matryoshka (sae/quantized_matryoshka.py:121-129). */
+int qsae_decode_matryoshka_split(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
+                                 const int32_t* level_sizes, const void* tq, const void* s3, const float* bias,
+                                 int allow_bias, float* levels, unsigned long long* l0_counts, qsae_stream_t stream);
+
 /* -- small elementwise steps (each operation rounded separately, as in the reference's ATen sequence) -------- */
 /* out[i] = (residual[i] - recon[i]) * scale: the residual handed to the next stage of ResidualQuantizedSAE
  * (sae/residual_quantized.py:67, scale = 2).  out may alias residual. */

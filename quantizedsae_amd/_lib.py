@@ -79,6 +79,12 @@ SIGNATURES = {
     "qsae_encode_bits_prefilter_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, _i, _vp]),
     "qsae_pack_matryoshka_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "qsae_decode_matryoshka_sparse": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "qsae_split_dec_supported": (_i, [_i, _i, _i]),
+    "qsae_expand_codes_bf16_bytes": (_sz, [_i, _i]),
+    "qsae_expand_codes_bf16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "qsae_decode_ternary_dense_split": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
+    "qsae_split_scale_bf16": (_i, [_vp, _i, _vp, _vp]),
+    "qsae_decode_matryoshka_split": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_pack_bits_gt": (_i, [_vp, _i64, _i, _i, _f, _vp, _i64, _vp]),
     "qsae_residual_update": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
     "qsae_threshold_ge": (_i, [_vp, _sz, _f, _vp, _vp]),

@@ -11,6 +11,7 @@
 // 2*scale; all levels run in ONE K-walk whose accumulator is written out at every level
 // boundary (the reference launches one GEMM per level and clones the running sum).
 #include "gemm_mfma_f32.h"
+#include "split_dec_bf16.h"
 
 namespace qsae {
 
@@ -512,4 +513,78 @@ extern "C" int qsae_decode_matryoshka_sparse(const uint32_t* zbits, int64_t word
 #undef QSAE_SP_LAUNCH
     QSAE_LAUNCH_CHECK();
     return QSAE_OK;
+}
+
+// ---- the same decoders on the bf16 matrix pipe (split_dec_bf16.h) ---------------------------------------------------------
+extern "C" int qsae_split_dec_supported(int B, int H, int D) { return split_dec_shape_ok(B, H, D) ? 1 : 0; }
+
+extern "C" size_t qsae_expand_codes_bf16_bytes(int D, int H) {
+    if (D != kSdBN || H <= 0 || H % (2 * kSdBK) != 0) return 0;
+    return static_cast<size_t>(H) * static_cast<size_t>(D) * 2;
+}
+
+extern "C" int qsae_expand_codes_bf16(const uint32_t* codes2, int D, int H, void* tq, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(D > 0 && H > 0 && codes2 && tq, "D > 0, H > 0, non-null pointers");
+    QSAE_CHECK_SUPPORTED(D == kSdBN && H % (2 * kSdBK) == 0, "D must be 512 and H a multiple of 64");
+    QSAE_CHECK_ARG(aligned16(tq), "tq must be 16-byte aligned");
+    const long long total = static_cast<long long>(H / kSdBK) * D * 4;
+    hipLaunchKernelGGL(expand_codes_bf16_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), codes2, D, H, static_cast<sd_u32x4*>(tq));
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+extern "C" int qsae_decode_ternary_dense_split(const float* h, int64_t ld, int B, int H, const void* tq, int D, float* recon,
+                                               qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0 && D > 0, "B >= 0, H > 0, D > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(h && tq && recon, "null pointer");
+    QSAE_CHECK_SUPPORTED(split_dec_shape_ok(B, H, D), "D must be 512 and H a multiple of 64 (use qsae_decode_ternary_dense)");
+    QSAE_CHECK_ARG(ld >= H && ld % 4 == 0, "ld >= H and ld a multiple of 4 required");
+    QSAE_CHECK_ARG(aligned16(h) && aligned16(tq), "h and tq must be 16-byte aligned");
+    SdArgs a{};
+    a.h = h; a.ld = ld; a.tq = static_cast<const __bf16*>(tq); a.B = B; a.H = H; a.out = recon;
+    return launch_split_dec<0>(a, as_stream(stream));
+}
+
+extern "C" int qsae_split_scale_bf16(const float* scale, int H, void* s3, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(H > 0 && scale && s3, "H > 0, non-null pointers");
+    QSAE_CHECK_ARG(aligned16(s3) && H % 8 == 0, "s3 must be 16-byte aligned and H a multiple of 8");
+    hipLaunchKernelGGL(split_scale_bf16_kernel, dim3((H + 255) / 256), dim3(256), 0, as_stream(stream), scale, H,
+                       static_cast<__bf16*>(s3));
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+extern "C" int qsae_decode_matryoshka_split(const uint32_t* zbits, int64_t words_ld, int B, int H, int D, int n_bits,
+                                            const int32_t* level_sizes, const void* tq, const void* s3, const float* bias,
+                                            int allow_bias, float* levels, unsigned long long* l0_counts,
+                                            qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && H > 0 && D > 0, "B >= 0, H > 0, D > 0 required");
+    QSAE_CHECK_ARG(n_bits >= 1 && n_bits <= kMaxLevels, "1 <= n_bits <= 8 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(zbits && tq && s3 && levels, "null pointer");
+    QSAE_CHECK_ARG(words_ld >= (H + 31) / 32, "words_ld < ceil(H/32)");
+    QSAE_CHECK_SUPPORTED(split_dec_shape_ok(B, H, D), "D must be 512 and H a multiple of 64 (use qsae_decode_matryoshka)");
+    QSAE_CHECK_ARG(aligned16(tq) && aligned16(s3), "tq and s3 must be 16-byte aligned");
+    QSAE_CHECK_SUPPORTED(static_cast<unsigned long long>(B) * static_cast<unsigned long long>(words_ld) * 4ull < (1ull << 32),
+                         "z bits of one call must stay below 4 GiB");
+    LevelTable lv;
+    const int rc = make_levels(H, n_bits, 1.0f, level_sizes, lv);
+    if (rc != QSAE_OK) return rc;
+    for (int i = 0; i < n_bits; ++i)
+        QSAE_CHECK_SUPPORTED(lv.end[i] % 64 == 0, "level boundaries must be multiples of 64 (use qsae_decode_matryoshka)");
+    hipStream_t s = as_stream(stream);
+    if (l0_counts) {
+        QSAE_HIP(hipMemsetAsync(l0_counts, 0, sizeof(unsigned long long) * n_bits, s));
+        long long blocks = B < 2048 ? B : 2048;
+        hipLaunchKernelGGL(count_bits_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, zbits, words_ld, B,
+                           H / 32, lv, l0_counts);
+        QSAE_LAUNCH_CHECK();
+    }
+    SdArgs a{};
+    a.zbits = zbits; a.words_ld = words_ld; a.s3 = static_cast<const __bf16*>(s3); a.tq = static_cast<const __bf16*>(tq);
+    a.B = B; a.H = H; a.out = levels; a.bias = allow_bias ? bias : nullptr; a.n_levels = n_bits;
+    for (int i = 0; i < kSdMaxLevels; ++i) a.level_end[i] = i < n_bits ? lv.end[i] : H;
+    return launch_split_dec<1>(a, s);
 }

@@ -1,0 +1,345 @@
+// split_dec_bf16.h -- dense decoders with integer-valued dictionaries on the bf16 matrix pipe.
+//
+// Role: recon[b][d] = sum_k a[b][k] * t[d][k] over ALL hidden units k, for dictionaries whose entries are exactly
+// representable in bf16: the ternary decoder (reference sae/ternary.py:41-52: hard = sign(w) (|w| >= 0.5) in {-1,0,+1},
+// a = ReLU latents) and the matryoshka / residual decoders (sae/quantized_matryoshka.py:67-124: S/2 in {-1,0,+1},
+// a = z_k * 2 scale_k with z in {0,1}).  The exact-fp32 kernels (dense_dec.hip over gemm_mfma_f32.h) contract these with
+// v_mfma_f32_32x32x2_f32 at 1/16 of the bf16 rate although one operand needs two bits.  Here only the ACTIVATION operand
+// carries fp32 information, and it is split exactly into three bf16 terms:
+//     a = a1 + a2 + a3,  a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// (both subtractions are exact -- the operands are within a factor two of each other -- and the last remainder has at
+// most eight significant bits: 8 + 8 + 8 = the 24 bits of an fp32 mantissa).  Every product a_i * t is then exact in
+// fp32, and the three passes accumulate into ONE fp32 accumulator: what is left is fp32 accumulation rounding, of the
+// same size as the fp32 kernel's (which rounds once per term), in another order.  Parity: 1e-5 relative against the
+// fp64-accumulating oracle, like the fp32 kernels (tests/test_split_dec_gpu.py measures both).
+//
+// Data movement, one workgroup (512 threads, 8 waves as 2 x 4) per 128 activation rows and ALL 512 output columns, so the
+// fp32 activations (8.6 GB at 65536 x 32768) leave HBM exactly once:
+//   * per K step of 32 hidden units: the fp32 tile [128][32] comes through registers (asm loads issued one K step
+//     ahead), is split into three bf16 planes [128][32] and written to LDS (24 KiB); the dictionary tile [512][32] bf16
+//     (32 KiB) is a linear LDS-DMA copy: the dictionary is expanded from the 2-bit codes ONCE per checkpoint into the
+//     image the kernel reads (qsae_expand_codes_bf16: K-step-major, chunks pre-swizzled), every workgroup streams the
+//     same 32 MiB in the same order (L2 / memory-side cache hits after the first toucher);
+//   * LDS image of both tiles: row = 64 bytes = four 16-byte chunks (8 k each); chunk c of row r sits at position
+//     c ^ ((r >> 2) & 3): the sixteen lanes of a ds_read_b128 group hit sixteen distinct bank groups;
+//   * per wave and K step: 48 v_mfma_f32_32x32x16_bf16 (2 row tiles x 4 column tiles x 3 planes x 2 k16) on 20
+//     ds_read_b128, 128 accumulator registers; two stages of 56 KiB, one counted s_waitcnt + s_barrier per step.
+// Matryoshka: the K walk writes the accumulator (+ bias) at every level boundary (one pass for all levels, like the fp32
+// kernel); the a operand is built from the z bit and a per-unit table of the three bf16 terms of 2 scale_k.
+#pragma once
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace qsae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float sd_f32x4 __attribute__((ext_vector_type(4)));
+typedef float sd_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned sd_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSdThreads = 512;
+constexpr int kSdBM = 128, kSdBN = 512, kSdBK = 32;
+constexpr int kSdPlane = kSdBM * kSdBK * 2;         // one bf16 plane of the activation tile: 8 KiB
+constexpr int kSdA = 3 * kSdPlane;                  // 24 KiB
+constexpr int kSdB = kSdBN * kSdBK * 2;             // dictionary tile: 32 KiB
+constexpr int kSdStage = kSdA + kSdB;               // 56 KiB
+constexpr int kSdLds = 2 * kSdStage;                // two stages
+constexpr int kSdDmaPerWave = (kSdB / 1024) / 8;    // 1-KiB LDS-DMA pieces per wave and K step
+constexpr int kSdMaxLevels = 8;
+
+struct SdArgs {
+    // MODE 0: fp32 activations
+    const float* h;            // [B][ld]
+    long long ld;
+    // MODE 1: z bits and the three bf16 terms of 2 * scale per hidden unit
+    const uint32_t* zbits;     // [B][words_ld], bit j of word w = unit 32 w + j
+    long long words_ld;
+    const __bf16* s3;          // [3][H]
+    // both
+    const __bf16* tq;          // dictionary image [H/32][512][32] (qsae_expand_codes_bf16)
+    int B, H;
+    float* out;                // MODE 0: recon [B][512]; MODE 1: levels [n][B][512]
+    const float* bias;         // MODE 1: [512] or nullptr
+    int n_levels;              // MODE 1
+    int level_end[kSdMaxLevels];   // exclusive end (hidden index, multiple of 32) of each level
+};
+
+// a = t0 + t1 + t2 exactly (see the header comment)
+__device__ __forceinline__ void sd_split3(const sd_f32x4& lo, const sd_f32x4& hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? lo[e] : hi[e - 4];
+        const __bf16 t0 = static_cast<__bf16>(v);
+        const float r1 = v - static_cast<float>(t0);
+        const __bf16 t1 = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(t1);
+        p0[e] = t0;
+        p1[e] = t1;
+        p2[e] = static_cast<__bf16>(r2);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kSdThreads)
+split_dec_bf16_kernel(SdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sd_smem[];
+    constexpr int NA = MODE == 0 ? 2 : 4;            // vector-memory operations per activation stage and thread
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int m0 = blockIdx.x * kSdBM;
+    const int nsteps = a.H / kSdBK;
+
+    // ---- loader mapping: thread t stages chunk lc (8 k) of tile row lrow -------------------------------------------
+    const int lrow = tid >> 2, lc = tid & 3;
+    const int grow = (m0 + lrow) < a.B ? (m0 + lrow) : a.B - 1;
+    const unsigned a_dst = static_cast<unsigned>(lrow * 64 + ((lc ^ ((lrow >> 2) & 3)) << 4));   // inside a plane
+    // MODE 0: byte offset of this thread's 32 bytes inside its row; per step + 128
+    const char* arow = MODE == 0 ? reinterpret_cast<const char*>(a.h + static_cast<long long>(grow) * a.ld) + lc * 32 : nullptr;
+    const unsigned zoff = static_cast<unsigned>(static_cast<long long>(grow) * a.words_ld * 4);     // MODE 1
+    const __bf16* s3p0 = a.s3;
+    const __bf16* s3p1 = a.s3 + a.H;
+    const __bf16* s3p2 = a.s3 + 2ll * a.H;
+
+    sd_f32x4 raw[2][2];                              // MODE 0: the 8 floats of a stage, two stages in flight
+    sd_u32x4 rawp[2][3];                             // MODE 1: the three bf16 term chunks ...
+    unsigned rawz[2];                                //          ... and the z word
+    auto issue_a = [&](int set, int step) __attribute__((always_inline)) {
+        step = step < nsteps ? step : nsteps - 1;    // past the end: the last stage again (into a buffer nobody reads)
+        if constexpr (MODE == 0) {
+            const char* src = arow + static_cast<long long>(step) * (kSdBK * 4);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[set][0]) : "v"(src));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(raw[set][1]) : "v"(src));
+        } else {
+            // scalar base + 32-bit lane offset (the host checks B * words_ld * 4 < 2^32): two registers of addressing
+            // instead of four 64-bit pointers
+            const unsigned zo = zoff + static_cast<unsigned>(step) * 4u;
+            const unsigned so = static_cast<unsigned>(lc * 16) + static_cast<unsigned>(step) * (kSdBK * 2);
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rawz[set]) : "v"(zo), "s"(a.zbits));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rawp[set][0]) : "v"(so), "s"(s3p0));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rawp[set][1]) : "v"(so), "s"(s3p1));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rawp[set][2]) : "v"(so), "s"(s3p2));
+        }
+    };
+    // wait until at most N vector-memory operations issued after this set are outstanding: the set has landed.  The
+    // statement names the set's registers as read-write operands, so every use of the data depends on it.  (`set` is a
+    // constant at every call site after inlining; the count has to be an immediate: one lambda per count.)
+#define QSAE_SD_LANDED(NAME, N)                                                                                                 \
+    auto NAME = [&](int set) __attribute__((always_inline)) {                                                                   \
+        if constexpr (MODE == 0)                                                                                                \
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(raw[set][0]), "+v"(raw[set][1]) : "n"(N));                                \
+        else                                                                                                                    \
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rawz[set]), "+v"(rawp[set][0]), "+v"(rawp[set][1]), "+v"(rawp[set][2])   \
+                         : "n"(N));                                                                                             \
+    }
+    QSAE_SD_LANDED(landed_first, NA);
+    QSAE_SD_LANDED(landed_loop, kSdDmaPerWave + NA);
+    QSAE_SD_LANDED(landed_all, 0);
+#undef QSAE_SD_LANDED
+    auto convert_a = [&](int set, int buf) __attribute__((always_inline)) {
+        char* dst = sd_smem + buf * kSdStage + a_dst;
+        if constexpr (MODE == 0) {
+            bf16x8 p0, p1, p2;
+            sd_split3(raw[set][0], raw[set][1], p0, p1, p2);
+            *reinterpret_cast<bf16x8*>(dst) = p0;
+            *reinterpret_cast<bf16x8*>(dst + kSdPlane) = p1;
+            *reinterpret_cast<bf16x8*>(dst + 2 * kSdPlane) = p2;
+        } else {
+            // a_k = z_k ? (the three terms of 2 scale_k) : 0: the unit's bit widened to a 16-bit mask
+            const unsigned bits = (rawz[set] >> (8 * lc)) & 0xFFu;
+            sd_u32x4 mask;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned lo = 0u - ((bits >> (2 * q)) & 1u), hi = 0u - ((bits >> (2 * q + 1)) & 1u);
+                mask[q] = (lo & 0xFFFFu) | (hi & 0xFFFF0000u);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<sd_u32x4*>(dst + p * kSdPlane) = rawp[set][p] & mask;
+        }
+    };
+    // dictionary tile of K step `step`: a linear copy of 32 KiB, four 1-KiB pieces per wave
+    const char* tq_lane = reinterpret_cast<const char*>(a.tq) + wave * (kSdDmaPerWave * 1024) + lane * 16;
+    auto issue_dma = [&](int step, int buf) __attribute__((always_inline)) {
+        step = step < nsteps ? step : nsteps - 1;
+        const char* src = tq_lane + static_cast<long long>(step) * kSdB;
+        char* dst = sd_smem + buf * kSdStage + kSdA + wave * (kSdDmaPerWave * 1024);      // wave-uniform
+#pragma unroll
+        for (int j = 0; j < kSdDmaPerWave; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 1024), (lptr_t)(dst + j * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment read addressing -------------------------------------------------------------------------------
+    const int sw = (r >> 2) & 3;
+    unsigned choff[2];                                // byte offset of chunk (2 s + hh) of a row, s = k16 step
+#pragma unroll
+    for (int s = 0; s < 2; ++s) choff[s] = static_cast<unsigned>(((2 * s + hh) ^ sw) << 4);
+    const unsigned a_frag = static_cast<unsigned>((wm * 64 + r) * 64);
+    const unsigned b_frag = static_cast<unsigned>(kSdA + (wn * 128 + r) * 64);
+
+    sd_f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
+
+    // the bias of this lane's four columns, loaded (and waited for) here: a compiler-visible load still pending at the loop
+    // header would cost a full vmcnt(0) in every iteration
+    float bcols[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1 && a.bias) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bcols[nt] = a.bias[wn * 128 + nt * 32 + r];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(bcols[nt]));
+    // rows mfma_row(reg) = (reg & 3) + 8 (reg >> 2) + 4 hh of a 32-row tile, column r
+    auto write_out = [&](float* base, bool add_bias) {
+        // (an opaque zero in the row index: the 32 row offsets are otherwise hoisted out of the level loop and held in
+        // registers across the K walk -- 50 spilled VGPRs in the matryoshka build)
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = wn * 128 + nt * 32 + r;
+            const float bcol = bcols[nt];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + opaque + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (row < a.B) base[static_cast<long long>(row) * kSdBN + col] = add_bias ? acc[mt][nt][e] + bcol : acc[mt][nt][e];
+                }
+        }
+    };
+
+    // ---- prologue: stage 0 complete in buffer 0, activation loads of stage 1 in flight -----------------------------------
+    issue_dma(0, 0);
+    issue_a(0, 0);
+    issue_a(1, 1);
+    landed_first(0);                                         // (also retires the DMA, which is older)
+    convert_a(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // (a kernel-argument array indexed with a run-time value would be copied to scratch memory: select with constants)
+    auto end_step_of = [&](int l) __attribute__((always_inline)) {
+        int e = a.H;
+#pragma unroll
+        for (int q = 0; q < kSdMaxLevels; ++q) e = (l == q) ? a.level_end[q] : e;
+        return e / kSdBK;
+    };
+    // One K step.  The buffer / register-set index is a constant at both call sites (two inlined copies of the body): indexed
+    // with a run-time value the register sets would live in scratch memory.
+    auto kstep = [&](int i, int cur) __attribute__((always_inline)) {
+        const int nxt = cur ^ 1;
+        // queue order of this iteration: [activations of stage i+1: issued one iteration ago] [dictionary of stage i+1]
+        // [activations of stage i+2]
+        issue_dma(i + 1, nxt);
+        issue_a(cur, i + 2);                                 // (set `cur` was converted at the end of the previous iteration)
+        const char* st = sd_smem + cur * kSdStage;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 bf[4], af[2][3];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(st + b_frag + nt * (32 * 64) + choff[s]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[mt][p] = *reinterpret_cast<const bf16x8*>(st + p * kSdPlane + a_frag + mt * (32 * 64) + choff[s]);
+#pragma unroll
+            for (int p = 2; p >= 0; --p)                     // smallest terms first
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][p], bf[nt], acc[mt][nt], 0, 0, 0);
+        }
+        // stage i+1: its activations have had a whole iteration to arrive
+        landed_loop(nxt);
+        convert_a(nxt, nxt);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NA) : "memory");    // dictionary landed, planes written
+        __builtin_amdgcn_s_barrier();
+    };
+    // The K walk, level by level (MODE 0: one level that ends at H).  Level boundaries are multiples of 64 (host check), so
+    // every level is a whole number of step pairs and a boundary coincides with the end of a pair; an empty level writes
+    // the accumulator its predecessor wrote.
+    const int n_levels = MODE == 1 ? a.n_levels : 1;
+    int i = 0;
+#pragma unroll 1
+    for (int level = 0; level < n_levels; ++level) {
+        const int end = MODE == 1 ? end_step_of(level) : nsteps;
+#pragma unroll 1
+        for (; i < end; i += 2) {
+            kstep(i, 0);
+            kstep(i + 1, 1);
+        }
+        write_out(a.out + static_cast<long long>(level) * a.B * kSdBN, MODE == 1);
+        // the stores are younger than the loads already queued for the next level: drain everything once per level so that
+        // the counted waits of the loop keep meaning what they say
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // the register sets are dead from here on, but a landing load must not find them reused: tie them to a wait
+    landed_all(0);
+    landed_all(1);
+}
+
+// Dictionary image for the kernel above, from the 2-bit codes [D = 512][H / 16 words] (field f of word w = unit 16 w + f;
+// 0 -> 0, 1 -> +1, 3 -> -1): tq[step][n][pos][8] bf16 with pos = chunk ^ ((n >> 2) & 3).  One thread per 16-byte chunk.
+__global__ void __launch_bounds__(256)
+expand_codes_bf16_kernel(const uint32_t* __restrict__ codes, int D, int H, sd_u32x4* __restrict__ tq) {
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long long total = static_cast<long long>(H / kSdBK) * D * 4;
+    if (gid >= total) return;
+    const int pos = static_cast<int>(gid & 3);
+    const int n = static_cast<int>((gid >> 2) % D);
+    const int step = static_cast<int>((gid >> 2) / D);
+    const int c = pos ^ ((n >> 2) & 3);
+    const int k0 = step * kSdBK + 8 * c;                     // 8 consecutive units: half of one code word
+    const uint32_t word = codes[static_cast<long long>(n) * (H / 16) + (k0 >> 4)] >> (2 * (k0 & 15));
+    sd_u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t c0 = (word >> (4 * q)) & 3u, c1 = (word >> (4 * q + 2)) & 3u;
+        const uint32_t b0 = (c0 & 1u ? 0x3F80u : 0u) | (c0 & 2u ? 0x8000u : 0u);
+        const uint32_t b1 = (c1 & 1u ? 0x3F80u : 0u) | (c1 & 2u ? 0x8000u : 0u);
+        o[q] = b0 | (b1 << 16);
+    }
+    tq[gid] = o;
+}
+
+// s3[p][j] = the p-th bf16 term of 2 * scale[j]
+__global__ void __launch_bounds__(256)
+split_scale_bf16_kernel(const float* __restrict__ scale, int H, __bf16* __restrict__ s3) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    const float v = 2.0f * scale[j];
+    const __bf16 t0 = static_cast<__bf16>(v);
+    const float r1 = v - static_cast<float>(t0);
+    const __bf16 t1 = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(t1);
+    s3[j] = t0;
+    s3[static_cast<long long>(H) + j] = t1;
+    s3[2ll * H + j] = static_cast<__bf16>(r2);
+}
+
+// (H a multiple of 64: the K walk runs in pairs of 32-unit steps)
+inline bool split_dec_shape_ok(int B, int H, int D) { return B > 0 && D == kSdBN && H >= 2 * kSdBK && H % (2 * kSdBK) == 0; }
+
+template <int MODE>
+inline int launch_split_dec(const SdArgs& a, hipStream_t s) {
+    auto kern = split_dec_bf16_kernel<MODE>;
+    QSAE_SET_MAX_LDS_ONCE(kern, kSdLds);
+    hipLaunchKernelGGL(kern, dim3((a.B + kSdBM - 1) / kSdBM), dim3(kSdThreads), kSdLds, s, a);
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+}  // namespace qsae

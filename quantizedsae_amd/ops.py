@@ -632,6 +632,60 @@ def decode_ternary_dense(h: torch.Tensor, codes: torch.Tensor, D: int) -> torch.
     return recon
 
 
+# ---- dense decoders on the bf16 matrix pipe ----------------------------------------------------
+def split_dec_supported(B: int, H: int, D: int) -> bool:
+    return bool(_lib.load().qsae_split_dec_supported(int(B), int(H), int(D)))
+
+
+@_on_tensor_device
+def expand_codes_bf16(codes: torch.Tensor, D: int, H: int) -> torch.Tensor:
+    """2-bit codes [D, ceil(H/16)] (pack_ternary / pack_matryoshka) -> the bf16 dictionary image the split decoders
+    stream (opaque, 2 H D bytes; once per checkpoint)."""
+    _dev(codes, "codes", torch.int32)
+    lib = _lib.load()
+    nbytes = int(lib.qsae_expand_codes_bf16_bytes(D, H))
+    if nbytes == 0:
+        raise ValueError("shape not supported by the bf16 split decoders (D == 512, H % 64 == 0)")
+    tq = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=codes.device)
+    check(lib.qsae_expand_codes_bf16(_p(codes.contiguous()), D, H, _p(tq), _stream()))
+    return tq
+
+
+@_on_tensor_device
+def decode_ternary_dense_split(h: torch.Tensor, tq: torch.Tensor, D: int) -> torch.Tensor:
+    """decode_ternary_dense from three exact bf16 terms of h on v_mfma_f32_32x32x16_bf16 (fp32 accumulation)."""
+    _dev(h, "h", torch.float32)
+    B, H = h.shape
+    recon = torch.empty((B, D), dtype=torch.float32, device=h.device)
+    check(_lib.load().qsae_decode_ternary_dense_split(_p(h), h.stride(0) if B else H, B, H, _p(tq), D, _p(recon), _stream()))
+    return recon
+
+
+@_on_tensor_device
+def split_scale_bf16(scale: torch.Tensor) -> torch.Tensor:
+    """scale [H] (pack_matryoshka) -> the three bf16 terms of 2 * scale, [3, H] bfloat16."""
+    scale = _f32c(scale, "scale")
+    H = scale.shape[0]
+    s3 = torch.empty((3, H), dtype=torch.bfloat16, device=scale.device)
+    check(_lib.load().qsae_split_scale_bf16(_p(scale), H, _p(s3), _stream()))
+    return s3
+
+
+@_on_tensor_device
+def decode_matryoshka_split(zbits: torch.Tensor, H: int, D: int, n_bits: int, tq, s3, bias, allow_bias: bool, sizes=None):
+    """decode_matryoshka on the bf16 matrix pipe: -> (levels f32 [n_bits, B, D], l0_counts int64 [n_bits])."""
+    _dev(zbits, "zbits", torch.int32)
+    B = zbits.shape[0]
+    levels = torch.empty((n_bits, B, D), dtype=torch.float32, device=zbits.device)
+    counts = torch.zeros((n_bits,), dtype=torch.int64, device=zbits.device)
+    b = _f32c(bias, "bias") if bias is not None else None
+    keep, sp = _sizes_arg(sizes, n_bits)
+    check(_lib.load().qsae_decode_matryoshka_split(_p(zbits), zbits.stride(0) if B else (H + 31) // 32, B, H, D, n_bits, sp,
+                                                   _p(tq), _p(s3), _p(b), 1 if allow_bias else 0, _p(levels), _p(counts),
+                                                   _stream()))
+    return levels, counts
+
+
 # ---- matryoshka ------------------------------------------------------------------------------
 def matryoshka_sizes(H: int, n_bits: int):
     arr = (C.c_int32 * n_bits)()

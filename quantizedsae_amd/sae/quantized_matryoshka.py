@@ -102,10 +102,17 @@ class QuantizedMatryoshkaDecoder(nn.Module):
             st.update(codes=codes, scale=scale)
             if ops.decode_matryoshka_sparse_supported(self.out_features):
                 st["codes_rows"] = ops.pack_matryoshka_rows(w, wm)      # hidden-major copy for the sparse walk
+            ends = [sum(st["sizes"][:i + 1]) for i in range(self.n_bits)]
+            if ops.split_dec_supported(1, st["H"], self.out_features) and all(e % 64 == 0 for e in ends):
+                st["tq"] = ops.expand_codes_bf16(codes, self.out_features, st["H"])      # bf16 image for the split kernel
+                st["s3"] = ops.split_scale_bf16(scale)                                    # three bf16 terms of 2 scale
             return st
         return self._cache.get((self.weight, self.weight_mirror), build)
 
     # -- decode ---------------------------------------------------------------------------------
+    #: "auto" | "fp32": the dense decoder on the bf16 matrix pipe where the kernel covers the shape (out_features 512,
+    #: padded hidden size and level boundaries % 64 == 0), or always the exact-fp32 MFMA chain.  See STEWeights.precision.
+    precision = "auto"
     #: the sparse walk beats the dense contraction below ~12 % active units (measured: 15 ms at 16 %, 23 ms dense)
     SPARSE_MAX_ACTIVE_FRACTION = 0.12
 
@@ -136,6 +143,11 @@ class QuantizedMatryoshkaDecoder(nn.Module):
             levels, counts = ops.decode_matryoshka_sparse(zbits, st["H"], self.out_features, self.n_bits,
                                                           st["codes_rows"], st["scale"], self.bias.detach(),
                                                           self.allow_bias, st["sizes"])
+        elif self.precision != "fp32" and "tq" in st and B * zbits.stride(0) * 4 < (1 << 32):
+            # dense activations: z_j * 2 scale_j as three exact bf16 terms against the {-1, 0, +1} dictionary on the bf16
+            # matrix pipe (fp32 accumulation; qsae_decode_matryoshka_split)
+            levels, counts = ops.decode_matryoshka_split(zbits, st["H"], self.out_features, self.n_bits, st["tq"], st["s3"],
+                                                         self.bias.detach(), self.allow_bias, st["sizes"])
         else:
             levels, counts = ops.decode_matryoshka(zbits, st["H"], self.out_features, self.n_bits, st["codes"],
                                                    st["scale"], self.bias.detach(), self.allow_bias, st["sizes"])

@@ -33,15 +33,43 @@ class STEWeights(nn.Module):
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def codes(self) -> torch.Tensor:
+        return self._packed()["c"]
+
+    #: "auto" | "split" | "fp32".  split: the latent as three exact bf16 terms against the {-1, 0, +1} dictionary on the
+    #: bf16 matrix pipe, fp32 accumulation (qsae_decode_ternary_dense_split) -- every product exact, the sum rounded in
+    #: another order than the fp32 kernel's (both within 1e-5 of the fp64-accumulating oracle); fp32: the exact-fp32 MFMA
+    #: chain.  auto = split where the kernel covers the shape (input_dim 512, hidden_dim % 64 == 0), else fp32.
+    precision = "auto"
+
+    def _packed(self) -> dict:
         if self.threshold != 0.5:
             raise NotImplementedError("only the reference threshold 0.5 is packed")
-        return self._cache.get((self.weight,), lambda: {"c": ops.pack_ternary(self.weight.detach())})["c"]
+        return self._cache.get((self.weight,), lambda: {"c": ops.pack_ternary(self.weight.detach())})
+
+    def dictionary_bf16(self) -> torch.Tensor:
+        """The bf16 image of the dictionary the split kernel streams (once per checkpoint, 2 H D bytes)."""
+        st = self._packed()
+        if "tq" not in st:
+            D, H = self.weight.shape
+            st["tq"] = ops.expand_codes_bf16(st["c"], D, H)
+        return st["tq"]
+
+    def resolved_precision(self, rows: int) -> str:
+        if self.precision not in ("auto", "split", "fp32"):
+            raise ValueError(f"precision must be 'auto', 'split' or 'fp32', got {self.precision!r}")
+        D, H = self.weight.shape
+        ok = rows > 0 and ops.split_dec_supported(rows, H, D)
+        if self.precision == "split" and not ok:
+            raise ValueError(f"STEWeights: the bf16 split decoder needs input_dim 512 and hidden_dim % 64 == 0 (got {D}, {H})")
+        return "split" if (ok and self.precision != "fp32") else "fp32"
 
     def forward(self, x):
         with torch.no_grad():
             x = require_device_input(x, "x")
             if x.dtype != torch.float32 or x.stride(1) != 1:
                 x = x.float().contiguous()
+            if self.resolved_precision(x.shape[0]) == "split" and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+                return ops.decode_ternary_dense_split(x, self.dictionary_bf16(), self.weight.shape[0])
             return ops.decode_ternary_dense(x, self.codes(), self.weight.shape[0])
 
     def init_mask(self, sparsity):

@@ -299,6 +299,47 @@ def _(zbits, H, D, n_bits, codes, scale, bias, allow_bias, sizes, sparse):
     return _f32((n_bits, zbits.shape[0], D), zbits), torch.empty((n_bits,), dtype=torch.int64, device=zbits.device)
 
 
+@_op("expand_codes_bf16")
+def _expand_codes_bf16(codes: Tensor, D: int, H: int) -> Tensor:
+    return _ops.expand_codes_bf16(codes, D, H)
+
+
+@_expand_codes_bf16.register_fake
+def _(codes, D, H):
+    return torch.empty((H * D,), dtype=torch.bfloat16, device=codes.device)
+
+
+@_op("decode_ternary_dense_split")
+def _decode_ternary_dense_split(h: Tensor, tq: Tensor, D: int) -> Tensor:
+    return _ops.decode_ternary_dense_split(h, tq, D)
+
+
+@_decode_ternary_dense_split.register_fake
+def _(h, tq, D):
+    return _f32((h.shape[0], D), h)
+
+
+@_op("split_scale_bf16")
+def _split_scale_bf16(scale: Tensor) -> Tensor:
+    return _ops.split_scale_bf16(scale)
+
+
+@_split_scale_bf16.register_fake
+def _(scale):
+    return torch.empty((3, scale.shape[0]), dtype=torch.bfloat16, device=scale.device)
+
+
+@_op("decode_matryoshka_split")
+def _decode_matryoshka_split(zbits: Tensor, H: int, D: int, n_bits: int, tq: Tensor, s3: Tensor, bias: Optional[Tensor],
+                             allow_bias: bool, sizes: Optional[List[int]]) -> Tuple[Tensor, Tensor]:
+    return _ops.decode_matryoshka_split(zbits, H, D, n_bits, tq, s3, bias, allow_bias, sizes)
+
+
+@_decode_matryoshka_split.register_fake
+def _(zbits, H, D, n_bits, tq, s3, bias, allow_bias, sizes):
+    return _f32((n_bits, zbits.shape[0], D), zbits), torch.empty((n_bits,), dtype=torch.int64, device=zbits.device)
+
+
 @_op("pack_bits_gt")
 def _pack_bits_gt(dense: Tensor, thr: float) -> Tensor:
     return _ops.pack_bits_gt(dense, thr)
@@ -490,6 +531,22 @@ def decode_matryoshka_sparse(zbits, H, D, n_bits, codes_rows, scale, bias, allow
                                None if sizes is None else [int(s) for s in sizes], True)
 
 
+def expand_codes_bf16(codes, D, H):
+    return Q.expand_codes_bf16(codes, int(D), int(H))
+
+
+def decode_ternary_dense_split(h, tq, D):
+    return Q.decode_ternary_dense_split(h, tq, int(D))
+
+
+def split_scale_bf16(scale):
+    return Q.split_scale_bf16(scale)
+
+
+def decode_matryoshka_split(zbits, H, D, n_bits, tq, s3, bias, allow_bias, sizes=None):
+    return Q.decode_matryoshka_split(zbits, H, D, n_bits, tq, s3, bias, allow_bias, None if sizes is None else [int(v) for v in sizes])
+
+
 def pack_bits_gt(dense, thr):
     return Q.pack_bits_gt(dense, float(thr))
 
@@ -542,6 +599,7 @@ def quantize_bits(x, n_bits, scale_factor, signed=True):
 prefilter_supported = _ops.prefilter_supported
 encode_bits_prefilter_supported = _ops.encode_bits_prefilter_supported
 decode_matryoshka_sparse_supported = _ops.decode_matryoshka_sparse_supported
+split_dec_supported = _ops.split_dec_supported
 matryoshka_sizes = _ops.matryoshka_sizes
 binary_row_bytes = _ops.binary_row_bytes
 binary_forward_prefilter_submit = _ops.binary_forward_prefilter_submit
