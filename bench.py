@@ -38,7 +38,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0                          # dense (the ~5 PF headl
 WEIGHT_BYTES_PER_BATCH = 4 * H * D + 4 * H + (H * D * N_BITS) // 8 + 4 * D      # 75 630 592 B
 
 
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")      # newest first
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")      # newest first
 TRAFFIC_SOURCE = None
 
 
@@ -177,8 +177,11 @@ def secondary_configs(device, x):
     with torch.no_grad():
         m = TernarySparseAutoencoder(D, H)
         m.decoder.weight.normal_(0, 0.5)
-        run("config 3: TernarySparseAutoencoder(512,32768), dense latent + reconstruction", m, lambda mm, xx: mm(xx), B,
-            4.0 * D * H)
+        run("config 3: TernarySparseAutoencoder(512,32768), dense latent + reconstruction (exact-fp32 MFMA encoder; decoder on the "
+            "bf16 matrix pipe: the latent as three exact bf16 terms against the {-1,0,+1} dictionary, fp32 accumulation)", m,
+            lambda mm, xx: mm(xx), B, 4.0 * D * H)
+        m.decoder.precision = "fp32"
+        run("config 3 with the exact-fp32 MFMA decoder (decoder.precision = 'fp32')", m, lambda mm, xx: mm(xx), B, 4.0 * D * H)
         m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)
         m.encoder[0].bias.fill_(-0.44)                     # -2.5 standard deviations of the latent: ~200 of 32768 units fire per row
         m.decoder.weight.uniform_(-1, 1)
@@ -189,7 +192,8 @@ def secondary_configs(device, x):
             submit=lambda mm, xx, sl: mm.forward_submit(xx, slot=sl))
         m.bits_path = "dense"
         m.decoder.SPARSE_MAX_ACTIVE_FRACTION = 0.0         # dense decoder whatever the activation density
-        run("config 4, same model through the exact dense kernels only (fp32 MFMA encoder + dense decoder)", m,
+        run("config 4, same model through the dense kernels only (exact-fp32 MFMA encoder for every latent + dense decoder on "
+            "the bf16 matrix pipe: z * 2 scale as three exact bf16 terms, fp32 accumulation)", m,
             lambda mm, xx: mm(xx), B, 4.0 * D * H)
         m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)
         m.decoder.weight.uniform_(-1, 1)

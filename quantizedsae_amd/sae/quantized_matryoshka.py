@@ -135,6 +135,11 @@ class QuantizedMatryoshkaDecoder(nn.Module):
         st = self.packed()
         B = zbits.shape[0]
         hint = self.active_fraction_hint()
+        if hint is None and sparse is None and B > 0:
+            # first decode of this model: measure this batch's density now (one host read, once per model) instead of
+            # guessing -- the two decoders round their sums in different orders, and a model that switched after its
+            # first call would return different low-order bits for the same batch
+            hint = self._active_fraction = float(ops.activation_counts_bits(zbits).sum().item()) / max(B * st["H"], 1)
         if sparse is None:
             sparse = hint is not None and hint < self.SPARSE_MAX_ACTIVE_FRACTION
         elif sparse and hint is not None and hint >= self.SPARSE_MAX_ACTIVE_FRACTION:

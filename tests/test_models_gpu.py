@@ -303,7 +303,11 @@ def test_matryoshka_prefilter_path_matches_dense_path(B, shift):
     model = load(QuantizedMatryoshkaSAE(D, H, 32, abs_range=4, n_bits=n_bits), sd)
     x = dev(S.activations(96, B, D))
     model.bits_path = "dense"
+    gs, ls = model(x)                                     # dense decoder on the bf16 matrix pipe (default where it applies)
+    model.decoder.precision = "fp32"                      # the exact-fp32 chain: what the sparse walk reproduces bit for bit
     g0, l0 = model(x)
+    for i in range(n_bits):                               # same sums, another rounding order
+        assert float(gs[i]) == float(g0[i]) and rel_err(host(ls[i]), host(l0[i])) < RECON_TOL
     model.bits_path = "auto"
     assert model.resolved_bits_path(B) == "prefilter"
     g1, l1 = model(x)
