@@ -12,7 +12,9 @@
  * events, one pinned word -- created on first use).  Calls may therefore be made from several
  * host threads and on several devices of one process; the caller makes the device of its
  * pointers current, as for any HIP library, and gives every concurrently running call its own
- * workspace.  The Python host side in quantizedsae_amd/ binds these with ctypes
+ * workspace.  (Several host threads: tested on hardware.  Several devices in ONE process: by
+ * construction only -- no box with two visible devices has run it yet; one process per GPU is the
+ * tested deployment.)  The Python host side in quantizedsae_amd/ binds these with ctypes
  * (INTEGRATION.md shows the stub a reference maintainer would add).
  *
  * Conventions
