@@ -198,8 +198,9 @@ def secondary_configs(device, x):
         m = QuantizedMatryoshkaSAE(D, H, top_k=32, abs_range=4, n_bits=4)
         m.decoder.weight.uniform_(-1, 1)
         m.decoder.weight_mirror.uniform_(-1, 1)
-        run("config 4 at random init (encoder bias 0: half of the units fire, dense kernels)", m, lambda mm, xx: mm(xx),
-            B, 4.0 * D * H)
+        run("config 4 at random init (encoder bias 0: half of the units fire): z bits by fp16 classification of every latent + "
+            "exact re-evaluation of the ~1 % inside the error band (qsae_encode_bits_band), decoder on the bf16 matrix pipe", m,
+            lambda mm, xx: mm(xx), B, 4.0 * D * H)
         run("baseline_sae: BaselineSparseAutoencoder(512,32768) top-32", BaselineSparseAutoencoder(D, H),
             lambda mm, xx: mm(xx), B, 2.0 * D * H + 2.0 * 32 * D, submit=lambda mm, xx, sl: mm.forward_submit(xx, slot=sl))
         m = ResidualQuantizedSAE(D, H, top_k=32, abs_range=1.5, n_bits=4)

@@ -295,6 +295,16 @@ int qsae_encode_bits_prefilter_submit(const float* x, const float* W, const floa
 int qsae_encode_bits_prefilter_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
                                       int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
                                       size_t workspace_bytes, int flagged, qsae_stream_t stream);
+/* The same bits when the activations are DENSE (an untrained encoder: half of the units fire; the lists of the call above
+ * overflow and every row would take the exact fp32 contraction): an fp16 MFMA pass classifies EVERY latent -- bit 1 above
+ * cutoff + eps_b, bit 0 below cutoff - eps_b -- and lists only the latents inside the band (~0.7 % of them), which are
+ * re-evaluated with the exact fp32 chain.  Bit-identical to qsae_encode_bits.  Rows with more than 1024 band entries or
+ * non-finite inputs are recomputed by the exact dense kernel (*flagged_rows).  D % 64 == 0, H % 32 == 0, else
+ * QSAE_ERR_UNSUPPORTED.  One host round trip per call. */
+size_t qsae_encode_bits_band_workspace_bytes(int B, int D, int H);
+int qsae_encode_bits_band(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                          int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                          size_t workspace_bytes, int* flagged_rows, qsae_stream_t stream);
 /* Hidden-major dictionary for the sparse decoder: codes_rows[j][ceil(D/16)] uint32, 2-bit two's-complement
  * fields of S_j/2 (same S as qsae_pack_matryoshka). */
 int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,

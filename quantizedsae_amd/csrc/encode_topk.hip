@@ -1600,13 +1600,13 @@ scatter_bit_rows_kernel(const uint32_t* __restrict__ src, const int* __restrict_
 struct BitsLayout {
     size_t tau, cnt, cnt_parts, cand, flags, xq, inv, margin, fx, fbits, total;
 };
-static BitsLayout bits_layout(int B, int D, int H) {
+static BitsLayout bits_layout(int B, int D, int H, int cap = kBitsCap) {
     BitsLayout L;
     size_t off = 0;
     L.tau = off;       off = align_up(off + static_cast<size_t>(B) * 4, 256);
     L.cnt = off;       off = align_up(off + static_cast<size_t>(B) * 4, 256);
     L.cnt_parts = off; off = align_up(off + static_cast<size_t>(B) * 4 * 7, 256);
-    L.cand = off;      off = align_up(off + static_cast<size_t>(B) * kBitsCap * 8, 256);
+    L.cand = off;      off = align_up(off + static_cast<size_t>(B) * cap * 8, 256);
     L.flags = off;     off = align_up(off + (static_cast<size_t>(B) + 4) * 4, 256);
     L.xq = off;        off = align_up(off + static_cast<size_t>(B) * D * 2, 256);
     L.inv = off;       off = align_up(off + static_cast<size_t>(B) * 4, 256);
@@ -1662,10 +1662,10 @@ static int bits_submit(const float* x, const float* W, const float* bias, const 
 
 // The exact dense kernel on the nflag flagged rows (count known to the host).
 static int bits_finish(const float* x, const float* W, const float* bias, int B, int D, int H, uint32_t* zbits,
-                       int64_t words_ld, char* ws, qsae_stream_t stream, int nflag) {
+                       int64_t words_ld, char* ws, qsae_stream_t stream, int nflag, int cap = kBitsCap) {
     if (nflag < 0 || nflag > B) return fail(QSAE_ERR_INVALID_ARG, "%s: flagged-row count out of range", __func__);
     hipStream_t s = as_stream(stream);
-    const BitsLayout L = bits_layout(B, D, H);
+    const BitsLayout L = bits_layout(B, D, H, cap);
     const int* flags = reinterpret_cast<const int*>(ws + L.flags);
     const int words = (H + 31) / 32;
     float* fx = reinterpret_cast<float*>(ws + L.fx);
@@ -1684,6 +1684,256 @@ static int bits_finish(const float* x, const float* W, const float* bias, int B,
                            rows, n, words, zbits, words_ld);
         QSAE_LAUNCH_CHECK();
     }
+    return QSAE_OK;
+}
+
+// ---- dense activations: classify EVERY latent with the fp16 pass, list only the uncertainty band -------------------------------
+// The candidate lists above hold every unit whose approximate latent reaches the cutoff -- all active units.  With dense
+// activations (an untrained encoder: half of the units fire) they overflow and every row falls back to the exact fp32
+// contraction (17.9 ms per 65536 x 32768 at 78 % of the fp32 matrix peak).  But |s^ - s| <= eps_b decides most bits by itself:
+//   s^ - c >  eps_b  =>  bit 1        s^ - c < -eps_b  =>  bit 0        otherwise (the band, ~0.7 % of the latents)  =>  exact chain
+// The fp16 LDS-DMA GEMM (activation rows on accumulator registers, hidden units on lanes) writes the certain bits with one
+// ballot per accumulator register -- 32 hidden units of one row = one word -- and appends the band to the row's list; the
+// resolve kernel then patches the listed bits from the exact chain.  Same bound, same exactness argument as above.
+constexpr int kBandCap = 1024;        // band entries per row (mean ~240 at the cutoff of a zero-mean latent; more -> flagged)
+
+template <int BM, int BN, int WMW, int WNW>
+struct EpiBitsBand {
+    static constexpr int WTM = BM / WMW, WTN = BN / WNW, MT = WTM / 32, NT = WTN / 32;
+    static constexpr int kThreads = 64 * WMW * WNW;
+    static constexpr int kCheckpoints = 0;
+    // Band entries of one tile are collected in LDS and appended to the rows' lists with ONE global atomic per row and
+    // tile (a global atomic with return per entry -- 22 M of them at 65536 x 32768, 1 % in the band -- doubled the
+    // kernel's time: 3.9 -> 7.5 ms).  Scratch: hits per tile row [BM] | list base per tile row [BM] | total | entries.
+    static constexpr int kTileCap = 2048;                     // entries per tile held in LDS (mean ~650 at 1 %); more go direct
+    static constexpr int kLdsFloats = 2 * BM + 4 + 3 * kTileCap;
+    static constexpr int kStoresPerFinish = 0;
+    struct Args {
+        const float* inv;      // [B] 1 / (row scale * weight scale)
+        const float* margin;   // [B] 2 eps_b
+        const float* bias;     // [H] or nullptr
+        uint32_t* zbits;       // [B][words_ld]
+        int64_t words_ld;
+        uint2* cand;           // [B][cap] band entries {approximate latent, hidden index}
+        int* cnt;              // [B], zeroed by the caller
+        int cap;
+    };
+    __device__ __forceinline__ void begin(const Args&, const TileCtx&) {}
+    __device__ __forceinline__ void end(const Args&, const TileCtx&) {}
+    __device__ __forceinline__ void init(const Args&, f32x16 (&acc)[MT][NT], const TileCtx&) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    }
+    __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
+        const float cut = __uint_as_float(QSAE_SIG_GT_BITS);
+        int* lcount = reinterpret_cast<int*>(c.lds_epi);
+        int* lbase = lcount + BM;
+        int* ltotal = lbase + BM;
+        uint32_t* ent = reinterpret_cast<uint32_t*>(ltotal + 4);
+        if (c.tid < BM) lcount[c.tid] = 0;
+        if (c.tid == 0) *ltotal = 0;
+        __syncthreads();
+        float bcol[NT];
+        bool col_ok[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+            col_ok[nt] = col < c.N;
+            bcol[nt] = (a.bias && col_ok[nt]) ? a.bias[col] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // lanes 0-31 carry activation row mfma_row(r, 0), lanes 32-63 row mfma_row(r, 1)
+                const int lrow = c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                const int row = c.m0 + lrow;
+                const bool row_ok = row < c.M;
+                const int rr = row_ok ? row : c.M - 1;
+                const float iv = a.inv[rr];
+                const float half = 0.5f * a.margin[rr] * 1.00001f;       // eps_b with slack for the roundings below
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col0 = c.n0 + c.wn * WTN + nt * 32;
+                    const float v = fmaf(acc[mt][nt][r], iv, bcol[nt]);
+                    const float d = v - cut;
+                    const bool live = row_ok && col_ok[nt];
+                    const bool one = live && d > half;
+                    const bool band = live && !(d > half) && !(d < -half);       // (NaN lands here: the resolve step flags the row)
+                    const unsigned long long m1 = __ballot(one);
+                    if (c.lane_col == 0 && row_ok && col0 < c.N)
+                        a.zbits[static_cast<int64_t>(row) * a.words_ld + (col0 >> 5)] =
+                            c.lane_half ? static_cast<uint32_t>(m1 >> 32) : static_cast<uint32_t>(m1);
+                    if (band) {
+                        const uint32_t col = static_cast<uint32_t>(col0 + c.lane_col);
+                        const int slot = atomicAdd(ltotal, 1);
+                        if (slot < kTileCap) {
+                            const int p = atomicAdd(&lcount[lrow], 1);
+                            ent[3 * slot] = __float_as_uint(v);
+                            ent[3 * slot + 1] = col;
+                            ent[3 * slot + 2] = (static_cast<uint32_t>(lrow) << 16) | static_cast<uint32_t>(p & 0xFFFF);
+                        } else {                                                  // tile buffer full (rows without a finite margin)
+                            const int pos = atomicAdd(&a.cnt[row], 1);
+                            if (pos < a.cap) a.cand[static_cast<int64_t>(row) * a.cap + pos] = make_uint2(__float_as_uint(v), col);
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+        if (c.tid < BM) {
+            const int n = lcount[c.tid];
+            lbase[c.tid] = (n > 0 && c.m0 + c.tid < c.M) ? atomicAdd(&a.cnt[c.m0 + c.tid], n) : 0;
+        }
+        __syncthreads();
+        const int total = *ltotal < kTileCap ? *ltotal : kTileCap;
+        for (int e = c.tid; e < total; e += kThreads) {
+            const uint32_t rp = ent[3 * e + 2];
+            const int lrow = static_cast<int>(rp >> 16);
+            const int pos = lbase[lrow] + static_cast<int>(rp & 0xFFFFu);
+            if (pos < a.cap)
+                a.cand[static_cast<int64_t>(c.m0 + lrow) * a.cap + pos] = make_uint2(ent[3 * e], ent[3 * e + 1]);
+        }
+        __syncthreads();                                               // the scratch is reused by the next tile
+    }
+};
+
+// One wave per activation row: every listed latent lies inside the uncertainty band; its bit is decided by the exact fp32
+// chain (the transposed block gather of refine_topk_kernel) and, where it comes out 1, set in the row's word with a
+// no-return atomic -- the certain bits are already there.  LDS per wave: the transposed W tile + the index list (13 KiB:
+// three workgroups per CU; the row's bit vector is not staged).
+constexpr size_t kBandLdsPerWave = 64 * kRefTileStride * 4 + static_cast<size_t>(kBandCap) * 4;
+
+__global__ void __launch_bounds__(64 * kBitsWaves, 3)
+resolve_band_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, const float* __restrict__ x,
+                    const float* __restrict__ W, const float* __restrict__ bias, int B, int D, int H,
+                    uint32_t* __restrict__ zbits, int64_t words_ld, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char band_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kBitsWaves + wave;
+    if (b >= B) return;
+    float* wt = reinterpret_cast<float*>(band_smem + static_cast<size_t>(wave) * kBandLdsPerWave);
+    int* hidx = reinterpret_cast<int*>(wt + 64 * kRefTileStride);
+    auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };       // one wave's LDS operations execute in order
+    typedef const __attribute__((address_space(4))) int* cint_t;
+    const int m = ((cint_t)cnt)[b];
+    bool bad = m > kBandCap;
+    const uint2* list = cand + static_cast<int64_t>(b) * kBandCap;
+    if (!bad) {
+        for (int i = lane; i < m; i += 64) {
+            const uint2 r = list[i];
+            const float v = __uint_as_float(r.x);
+            bad |= (v != v) || r.y >= static_cast<uint32_t>(H);
+            hidx[i] = static_cast<int>(r.y);
+        }
+    }
+    if (__any(bad)) {                                                  // overflowing band / NaN latents: the exact kernel decides
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+        return;
+    }
+    lds_handoff();
+    typedef const __attribute__((address_space(4))) f32x4* cvec_t;
+    cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);
+    uint32_t* zrow = zbits + static_cast<int64_t>(b) * words_ld;
+    const int nblk = D / 32;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        const int h = (j < m) ? hidx[j] : hidx[j0];
+        float acc = bias ? bias[h] : 0.0f;
+        const float* rp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int jj = j0 + 8 * i + (lane >> 3);
+            jj = jj < m ? jj : j0;                                     // (past the list: the first row again, an L1 hit)
+            rp[i] = W + static_cast<int64_t>(hidx[jj]) * D + 4 * (lane & 7);
+        }
+        f32x4 st[kBitsSets][8];
+#pragma unroll
+        for (int q = 0; q < kBitsSets; ++q)
+            if (q < nblk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * q);
+            }
+        auto consume = [&](const f32x4 (&sv)[8], int t) {
+            f32x4 xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = xrow[8 * t + q];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+            lds_handoff();
+            const float* mine = wt + lane * kRefTileStride;
+            f32x4 w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
+            lds_handoff();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc = fmaf(xv[q][0], w[q][0], acc);
+                acc = fmaf(xv[q][1], w[q][1], acc);
+                acc = fmaf(xv[q][2], w[q][2], acc);
+                acc = fmaf(xv[q][3], w[q][3], acc);
+            }
+        };
+        for (int t = 0; t < nblk; t += kBitsSets) {
+#pragma unroll
+            for (int q = 0; q < kBitsSets; ++q) {
+                if (t + q < nblk) {
+                    consume(st[q], t + q);
+                    if (t + q + kBitsSets < nblk) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) st[q][i] = *reinterpret_cast<const f32x4*>(rp[i] + 32 * (t + q + kBitsSets));
+                    }
+                }
+            }
+        }
+        if (j < m && sig_gt_half(acc)) atomicOr(&zrow[h >> 5], 1u << (h & 31));
+    }
+}
+
+static bool bits_band_shape_ok(int B, int D, int H) {
+    return B > 0 && D % 64 == 0 && D <= kRefMaxD && H % 32 == 0 && H <= (1 << 20);
+}
+
+// Everything up to and including the band resolution (flags[0] = rows for the exact dense kernel afterwards).
+static int bits_band_submit(const float* x, const float* W, const float* bias, const _Float16* Wq, const float* meta,
+                            int B, int D, int H, uint32_t* zbits, int64_t words_ld, char* ws, qsae_stream_t stream) {
+    hipStream_t s = as_stream(stream);
+    const SweepProfile prof = take_sweep_profile();
+    const BitsLayout L = bits_layout(B, D, H, kBandCap);
+    int* cnt = reinterpret_cast<int*>(ws + L.cnt);
+    uint2* cand = reinterpret_cast<uint2*>(ws + L.cand);
+    int* flags = reinterpret_cast<int*>(ws + L.flags);
+    _Float16* xq = reinterpret_cast<_Float16*>(ws + L.xq);
+    float* inv = reinterpret_cast<float*>(ws + L.inv);
+    float* margin = reinterpret_cast<float*>(ws + L.margin);
+    const int words = (H + 31) / 32;
+    QSAE_HIP(hipMemsetAsync(flags, 0, sizeof(int), s));
+    QSAE_HIP(hipMemsetAsync(cnt, 0, static_cast<size_t>(B) * 4, s));
+    if (words_ld > words)
+        QSAE_HIP(hipMemset2DAsync(zbits + words, words_ld * 4, 0, (words_ld - words) * 4, B, s));
+    launch_x_prep(x, B, D, meta, xq, inv, margin, s);
+    QSAE_LAUNCH_CHECK();
+    using Epi = EpiBitsBand<256, 256, 4, 2>;
+    typename Epi::Args ea{inv, margin, bias, zbits, words_ld, cand, cnt, kBandCap};
+    if (prof.begin) QSAE_HIP(hipEventRecord(prof.begin, s));
+    int rc = launch_gemm_dma<Epi, 256, 256, true, 2>(reinterpret_cast<const float*>(xq), B, reinterpret_cast<const float*>(Wq), H,
+                                                     D / 2, ea, s, /*sweep=*/8);
+    if (prof.end) QSAE_HIP(hipEventRecord(prof.end, s));
+    if (rc != QSAE_OK) return rc;
+    const size_t lds = kBandLdsPerWave * kBitsWaves;
+    QSAE_SET_MAX_LDS_ONCE(resolve_band_kernel, 160 * 1024);
+    hipLaunchKernelGGL(resolve_band_kernel, dim3((B + kBitsWaves - 1) / kBitsWaves), dim3(64 * kBitsWaves), lds, s,
+                       cand, cnt, x, W, bias, B, D, H, zbits, words_ld, flags);
+    QSAE_LAUNCH_CHECK();
     return QSAE_OK;
 }
 
@@ -2118,4 +2368,40 @@ extern "C" int qsae_encode_bits_prefilter_finish(const float* x, const float* W,
     const int rc = bits_args_ok(__func__, x, W, Wq, meta, B, D, H, zbits, words_ld, workspace, workspace_bytes);
     if (rc != QSAE_OK) return rc;
     return bits_finish(x, W, bias, B, D, H, zbits, words_ld, static_cast<char*>(workspace), stream, flagged);
+}
+
+/* dense activations: every latent classified by the fp16 pass, the uncertainty band resolved exactly */
+extern "C" size_t qsae_encode_bits_band_workspace_bytes(int B, int D, int H) {
+    if (!bits_band_shape_ok(B, D, H)) return 0;
+    return bits_layout(B, D, H, kBandCap).total;
+}
+
+extern "C" int qsae_encode_bits_band(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                     int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                     size_t workspace_bytes, int* flagged_rows, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (flagged_rows) *flagged_rows = 0;
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(x && W && Wq && meta && zbits, "null pointer");
+    QSAE_CHECK_ARG(words_ld >= (H + 31) / 32, "words_ld < ceil(H/32)");
+    QSAE_CHECK_SUPPORTED(bits_band_shape_ok(B, D, H), "shape not covered (D % 64 == 0, H % 32 == 0; use qsae_encode_bits)");
+    QSAE_CHECK_ARG(aligned16(x) && aligned16(W) && aligned16(Wq), "x, W and Wq must be 16-byte aligned");
+    QSAE_CHECK_ARG(workspace && workspace_bytes >= bits_layout(B, D, H, kBandCap).total, "workspace too small");
+    QSAE_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t s = as_stream(stream);
+    int rc = bits_band_submit(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld, ws, stream);
+    if (rc != QSAE_OK) return rc;
+    const BitsLayout L = bits_layout(B, D, H, kBandCap);
+    ThreadDeviceCtx* ctx = nullptr;
+    rc = thread_device_ctx(&ctx);
+    if (rc != QSAE_OK) return rc;
+    *ctx->pinned = 0;
+    QSAE_HIP(hipMemcpyAsync(ctx->pinned, ws + L.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    QSAE_HIP(hipEventRecord(ctx->ev_copied, s));
+    QSAE_HIP(hipEventSynchronize(ctx->ev_copied));
+    const int nflag = *ctx->pinned;
+    if (flagged_rows) *flagged_rows = nflag;
+    if (nflag < 0 || nflag > B) return fail(QSAE_ERR_HIP, "%s: corrupt flagged-row count", __func__);
+    return bits_finish(x, W, bias, B, D, H, zbits, words_ld, ws, stream, nflag, kBandCap);
 }

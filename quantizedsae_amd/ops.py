@@ -209,6 +209,35 @@ def encode_bits_prefilter(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch
     return z, int(flagged.value)
 
 
+def encode_bits_band_supported(B: int, D: int, H: int) -> bool:
+    return B > 0 and int(_lib.load().qsae_encode_bits_band_workspace_bytes(B, D, H)) > 0
+
+
+@_on_tensor_device
+def encode_bits_band(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
+                     meta: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """z bits identical to encode_bits for DENSE activations: every latent classified by an fp16 MFMA pass, the
+    uncertainty band around the cutoff re-evaluated exactly.  Returns (zbits, rows that went through the exact kernel)."""
+    x, W = _f32c(x, "x"), _f32c(W, "W")
+    B, D = x.shape
+    H = W.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    lib = _lib.load()
+    if B == 0:
+        return torch.empty((0, (H + 31) // 32), dtype=torch.int32, device=x.device), 0
+    need = int(lib.qsae_encode_bits_band_workspace_bytes(B, D, H))
+    if need == 0:
+        raise ValueError("shape not supported by the fp16 band classification")
+    ws = _workspace(x.device, need)
+    words = (H + 31) // 32
+    z = torch.empty((B, words), dtype=torch.int32, device=x.device)
+    flagged = C.c_int(0)
+    kernel_timer.arm_sweep()
+    check(lib.qsae_encode_bits_band(_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, _p(z), words, _p(ws), ws.numel(),
+                                    C.byref(flagged), _stream()))
+    return z, int(flagged.value)
+
+
 @_on_tensor_device
 def encode_bits_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
                                  meta: torch.Tensor, slot: int = 0) -> "PendingForward":

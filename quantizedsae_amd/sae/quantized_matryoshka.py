@@ -220,24 +220,34 @@ class QuantizedMatryoshkaSAE(ops.GraphForwardMixin, SparseAutoencoder):
         st = self._enc_cache.get((lin.weight, lin.bias), build)
         return st["W"], st["b"]
 
-    #: "auto" | "dense" | "prefilter".  dense: every latent from the exact-fp32 MFMA contraction, dense decoder.
-    #: prefilter: the z bits from the fp16 candidate sweep (latents near the sigmoid cutoff re-evaluated exactly)
-    #: and the decoder walks the active units only -- bit-identical outputs, pays off when few units fire per row.
-    #: auto: prefilter for large batches until a batch shows dense activations (more than half of its rows
-    #: overflow their candidate lists, i.e. more than ~8 % of the units fire), then dense for this model.
+    #: "auto" | "dense" | "prefilter" | "band" -- how the z bits are computed; the bits are identical on every path.
+    #: dense: every latent from the exact-fp32 MFMA contraction.  prefilter: the fp16 candidate sweep lists the units near or
+    #: above the sigmoid cutoff, latents inside the error band are re-evaluated exactly; the decoder walks the active units --
+    #: pays off when few units fire per row.  band: an fp16 MFMA pass classifies EVERY latent and only the ~1 % inside the
+    #: band are re-evaluated (qsae_encode_bits_band) -- for dense activations, where the lists of the prefilter overflow.
+    #: auto: prefilter for large batches until a batch shows dense activations (more than half of its rows overflow their
+    #: candidate lists, i.e. more than ~8 % of the units fire), then band (dense where the shape is not covered) for this model.
     bits_path = "auto"
     _PREFILTER_MIN_ROWS = 2048
 
     def resolved_bits_path(self, batch_rows: int) -> str:
         path = self.bits_path
-        if path not in ("auto", "dense", "prefilter"):
-            raise ValueError(f"bits_path must be 'auto', 'dense' or 'prefilter', got {path!r}")
+        if path not in ("auto", "dense", "prefilter", "band"):
+            raise ValueError(f"bits_path must be 'auto', 'dense', 'prefilter' or 'band', got {path!r}")
         W, _ = self._encoder_params()
         ok = ops.encode_bits_prefilter_supported(batch_rows, self.input_dim, W.shape[0])
+        ok_band = ops.encode_bits_band_supported(batch_rows, self.input_dim, W.shape[0])
         if path == "auto":
             big = batch_rows >= self._PREFILTER_MIN_ROWS and W.shape[0] >= 2048
-            path = "prefilter" if (big and ok and not getattr(self, "_dense_regime", False)) else "dense"
+            if not big:
+                path = "dense"
+            elif getattr(self, "_dense_regime", False):
+                path = "band" if ok_band else "dense"
+            else:
+                path = "prefilter" if ok else ("band" if ok_band else "dense")
         if path == "prefilter" and not ok:
+            path = "dense"
+        if path == "band" and not ok_band:
             path = "dense"
         return path
 
@@ -258,12 +268,17 @@ class QuantizedMatryoshkaSAE(ops.GraphForwardMixin, SparseAutoencoder):
         with torch.no_grad():
             W, b = self._encoder_params()
             x = require_device_input(x, "x")
-            if (path or self.resolved_bits_path(x.shape[0])) == "prefilter":
+            path = path or self.resolved_bits_path(x.shape[0])
+            if path == "prefilter":
                 pw = self._prefilter_weights()
                 z, flagged = ops.encode_bits_prefilter(x.float(), W, b, pw["Wq"], pw["meta"])
                 self.last_flagged_rows = flagged
                 if flagged * 2 > x.shape[0]:                  # the exact fallback of half the rows costs what the dense kernel does
                     self._dense_regime = True
+                return z
+            if path == "band":
+                pw = self._prefilter_weights()
+                z, self.last_flagged_rows = ops.encode_bits_band(x.float(), W, b, pw["Wq"], pw["meta"])
                 return z
             return ops.encode_bits(x, W, b)
 

@@ -89,6 +89,17 @@ def _(x, W, bias, Wq, meta):
     return _i32((x.shape[0], (W.shape[0] + 31) // 32), x), _host_count()
 
 
+@_op("encode_bits_band")
+def _encode_bits_band(x: Tensor, W: Tensor, bias: Optional[Tensor], Wq: Tensor, meta: Tensor) -> Tuple[Tensor, Tensor]:
+    z, flagged = _ops.encode_bits_band(x, W, bias, Wq, meta)
+    return z, torch.tensor(flagged, dtype=torch.int64)
+
+
+@_encode_bits_band.register_fake
+def _(x, W, bias, Wq, meta):
+    return _i32((x.shape[0], (W.shape[0] + 31) // 32), x), _host_count()
+
+
 @_op("topk_rows", mutates=("latent",))
 def _topk_rows(latent: Tensor, k: int, zero_rest: bool) -> Tuple[Tensor, Tensor]:
     return _ops.topk_rows(latent, k, zero_rest)
@@ -438,6 +449,11 @@ def encode_bits_prefilter(x, W, bias, Wq, meta):
     return z, int(flagged)
 
 
+def encode_bits_band(x, W, bias, Wq, meta):
+    z, flagged = Q.encode_bits_band(x, W, bias, Wq, meta)
+    return z, int(flagged)
+
+
 def topk_rows(latent, k, zero_rest):
     return Q.topk_rows(latent, k, zero_rest)
 
@@ -598,6 +614,7 @@ def quantize_bits(x, n_bits, scale_factor, signed=True):
 # what has no tensor result (shape queries, handles of batches in flight) stays plain Python
 prefilter_supported = _ops.prefilter_supported
 encode_bits_prefilter_supported = _ops.encode_bits_prefilter_supported
+encode_bits_band_supported = _ops.encode_bits_band_supported
 decode_matryoshka_sparse_supported = _ops.decode_matryoshka_sparse_supported
 split_dec_supported = _ops.split_dec_supported
 matryoshka_sizes = _ops.matryoshka_sizes

@@ -315,7 +315,12 @@ def test_matryoshka_prefilter_path_matches_dense_path(B, shift):
         assert torch.equal(l0[i], l1[i]), i
         assert float(g0[i]) == float(g1[i])
     if shift == 0.0:
-        assert model.last_flagged_rows == B and model.resolved_bits_path(B) == "dense"
+        # dense activations: the model leaves the candidate lists for the band classification (same bits, same levels)
+        assert model.last_flagged_rows == B and model.resolved_bits_path(B) == "band"
+        g2, l2 = model(x)
+        assert model.last_flagged_rows == 0
+        for i in range(n_bits):
+            assert torch.equal(l0[i], l2[i]) and float(g0[i]) == float(g2[i])
     else:
         assert model.last_flagged_rows < B // 8 and model.resolved_bits_path(B) == "prefilter"
         # a CPU cross-check of the first rows against the oracle

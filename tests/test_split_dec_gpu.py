@@ -150,3 +150,27 @@ def test_models_take_the_split_decoders_by_default_and_fp32_on_request():
     assert all(torch.equal(a, b) for a, b in zip(g, g32))
     # (half of the units fire at random init: sums of ~2000 cancelling terms; the two kernels round them in different orders)
     assert all(rel_err(host(a), host(b).astype(np.float64)) < 1e-5 for a, b in zip(lv, lv32))
+
+
+# ---- dense-regime z bits: fp16 classification of every latent + exact resolution of the uncertainty band --------------------
+@pytest.mark.parametrize("B,Dm,H,shift", [(2500, 512, 8192, 0.0), (4096, 256, 4096, -1.0), (700, 128, 2048, 0.5),
+                                          (2048, 512, 32768, 0.0), (300, 512, 4128, -2.5)])
+def test_encode_bits_band_matches_exact(B, Dm, H, shift):
+    """qsae_encode_bits_band == qsae_encode_bits (the exact fp32 contraction; reference: encoder(x) then `latent > 0.5`,
+    sae/quantized_matryoshka.py:97-99,206-209) bit for bit, at activation densities from 0.6 % to 70 %, with rows the bound
+    cannot serve (NaN / inf) and rows of very different scale."""
+    sd = S.matryoshka_sae_params(300, Dm, H, enc_bias_sigmas=shift)
+    W, b = dev(sd["encoder.0.weight"]), dev(sd["encoder.0.bias"])
+    x = S.activations(301, B, Dm)
+    x[::9] *= 50.0
+    x[1::9] *= 1e-3
+    x[5, 3] = np.nan
+    x[77, 0] = np.inf
+    xd = dev(x)
+    assert ops.encode_bits_band_supported(B, Dm, H)
+    Wq, meta = ops.prefilter_pack_w(W, b)
+    z, flagged = ops.encode_bits_band(xd, W, b, Wq, meta)
+    want = ops.encode_bits(xd, W, b)
+    assert torch.equal(z, want)
+    assert 2 <= flagged <= 2 + B // 50                      # the two non-finite rows (+ rows whose band overflows: none expected)
+    dens = float(torch.ops.qsae.encode_bits(xd, W, b).view(torch.uint8).to(torch.int32).sum()) if False else None
