@@ -244,8 +244,7 @@ split_dec_bf16_kernel(SdArgs a) {
         issue_dma(i + 1, nxt);
         issue_a(cur, i + 2);                                 // (set `cur` was converted at the end of the previous iteration)
         const char* st = sd_smem + cur * kSdStage;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        auto k16 = [&](int s) __attribute__((always_inline)) {
             bf16x8 bf[4], af[2][3];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(st + b_frag + nt * (32 * 64) + choff[s]);
@@ -261,10 +260,14 @@ split_dec_bf16_kernel(SdArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][p], bf[nt], acc[mt][nt], 0, 0, 0);
-        }
-        // stage i+1: its activations have had a whole iteration to arrive
+        };
+        k16(0);
+        // stage i+1's activations have had most of an iteration to arrive; their split (VALU + three LDS writes per thread,
+        // into the OTHER buffer) sits between the two MFMA groups so that it issues in their shadows instead of holding
+        // every wave of the workgroup in front of the barrier with the matrix pipe idle
         landed_loop(nxt);
         convert_a(nxt, nxt);
+        k16(1);
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NA) : "memory");    // dictionary landed, planes written
         __builtin_amdgcn_s_barrier();
     };
