@@ -299,3 +299,32 @@ def test_row_sharded_mse_world_size_2_gloo():
     for _, mse, slow, _ in res:
         assert mse == pytest.approx(want, rel=1e-12)
         assert slow == 2.0
+
+
+def test_three_bf16_terms_carry_an_fp32_value_exactly():
+    """The arithmetic claim behind csrc/split_dec_bf16.h, checked on the CPU with an emulated round-to-nearest-even bf16:
+    t1 = bf16(v), t2 = bf16(v - t1), t3 = bf16(v - t1 - t2) -- both subtractions exact in fp32, t1 + t2 + t3 == v for every
+    finite fp32 v whose third term stays normal (|v| >= 2^-100 here), so v * t (t in {-1, 0, +1}) reaches the accumulator of
+    the bf16 matrix pipe without any rounding of its own."""
+    def bf16(a):
+        u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+    rng = np.random.default_rng(0)
+    mant = rng.integers(0, 1 << 23, 2_000_000, dtype=np.uint32)
+    expo = rng.integers(27, 250, 2_000_000, dtype=np.uint32)             # 2^-100 .. 2^122
+    sign = rng.integers(0, 2, 2_000_000, dtype=np.uint32)
+    v = ((sign << 31) | (expo << 23) | mant).view(np.float32)
+    v[:7] = [0.0, 1.0, -1.0, 3.0, np.float32(1) + np.float32(2 ** -23), 255.0, np.float32(2 ** -23)]
+    t1 = bf16(v)
+    r1 = (v - t1).astype(np.float32)
+    assert np.array_equal(r1.astype(np.float64), v.astype(np.float64) - t1.astype(np.float64))      # exact subtraction
+    t2 = bf16(r1)
+    r2 = (r1 - t2).astype(np.float32)
+    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - t2.astype(np.float64))
+    t3 = bf16(r2)
+    assert np.array_equal(t3, r2)                                         # the last remainder needs no rounding
+    total = t1.astype(np.float64) + t2.astype(np.float64) + t3.astype(np.float64)
+    assert np.array_equal(total, v.astype(np.float64))
+    assert np.abs(t2[t1 != 0]).max() <= 2.0 ** -8 * np.abs(t1[t1 != 0]).max()

@@ -256,3 +256,27 @@ def test_one_process_walks_over_two_devices():
         outs.append((lat.cpu(), rec.cpu(), small.cpu()))
     for o in outs[1:]:
         assert same_bits(o, outs[0])
+
+
+def test_small_batch_forward_is_capturable_in_a_hip_graph():
+    """The in-place path of small batches (dense encoder -> in-place top-k -> sparse decode) has no host read-back: the whole
+    forward can be captured once and replayed (torch.cuda.CUDAGraph), new inputs copied into the captured buffer; replays
+    return the eager bits.  (The candidate-sweep path of large batches reads its flagged-row count on the host.)"""
+    model = make_model(DEV)
+    model.decoder.packed()
+    xs = [batch(80 + i, 64, DEV) for i in range(3)]
+    want = [model(x) for x in xs]
+    static_x = xs[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = model(static_x)
+    for x, w in zip(xs, want):
+        static_x.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert same_bits(out[:2], w[:2])
