@@ -21,14 +21,25 @@ from .sharding import max_over_ranks, reduce_mse
 
 def stream_reconstruction_error(model, datasets: Iterable, device, *, batch_rows: int = 65536, world_size: int = 1,
                                 rank: int = 0, in_flight: int = 2, group=None) -> dict:
-    """Run ``model`` over this rank's rows of every dataset (``HiddenStatesTorchDataset``-like: ``iter_batches``) and
-    return the GLOBAL recon-MSE (all ranks' rows) plus this rank's counters.  ``in_flight`` = 2 uses the two-call
-    forward (compact outputs: the dense latent is not needed for the metric), 1 the blocking ``forward_compact``."""
+    """Run ``model`` (any of the five module classes) over this rank's rows of every dataset (``HiddenStatesTorchDataset``-
+    like: ``iter_batches``) and return the GLOBAL recon-MSE (all ranks' rows) plus this rank's counters.  ``in_flight`` = 2
+    uses the two-call forward where the model has one (BinarySAE / Baseline with compact outputs -- the dense latent is not
+    needed for the metric --, QuantizedMatryoshkaSAE), 1 the blocking forward."""
     dev = torch.device(device)
     sq = torch.zeros((), dtype=torch.float64, device=dev)
     rows = batches = 0
     flagged = []
+    compact = hasattr(model, "forward_compact")              # BinarySAE / Baseline: (idx, val, reconstruction), no dense latent
     submit = getattr(model, "forward_submit", None) if in_flight > 1 else None
+
+    def reconstruction(outs):
+        """The reconstruction in a forward()'s outputs, as the reference's adapters pick it (inference/framework.py:76-111):
+        last element of a tuple; the last level where that is a list of levels."""
+        rec = outs[-1]
+        if compact and len(outs) == 3 and not isinstance(rec, (list, tuple)) and rec.dim() == 0:
+            rec = outs[1]                                    # BinarySAE.forward: (latent, reconstruction, polarize_loss)
+        return rec[-1] if isinstance(rec, (list, tuple)) else rec
+
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     with torch.no_grad():
@@ -36,21 +47,20 @@ def stream_reconstruction_error(model, datasets: Iterable, device, *, batch_rows
 
         def finish(p):
             handle, xb = p
-            _idx, _val, recon = handle.result()
-            ops.sq_err_sum(recon, xb, sq)
-            flagged.append(int(getattr(model, "last_flagged_rows", 0)))
+            ops.sq_err_sum(reconstruction(handle.result()), xb, sq)
+            flagged.append(int(getattr(model, "last_flagged_rows", 0) or 0))
 
         for ds in datasets:
             for xb in ds.iter_batches(batch_rows, dev, world_size=world_size, rank=rank):
                 if submit is not None:
-                    h = submit(xb, slot=batches % 2, want_dense=False)
+                    h = submit(xb, slot=batches % 2, want_dense=False) if compact else submit(xb, slot=batches % 2)
                     if pending is not None:
                         finish(pending)
                     pending = (h, xb)
                 else:
-                    _idx, _val, recon = model.forward_compact(xb)
-                    ops.sq_err_sum(recon, xb, sq)
-                    flagged.append(int(getattr(model, "last_flagged_rows", 0)))
+                    outs = model.forward_compact(xb) if compact else model(xb)
+                    ops.sq_err_sum(reconstruction(outs), xb, sq)
+                    flagged.append(int(getattr(model, "last_flagged_rows", 0) or 0))
                 rows += xb.shape[0]
                 batches += 1
         if pending is not None:
@@ -58,6 +68,8 @@ def stream_reconstruction_error(model, datasets: Iterable, device, *, batch_rows
     torch.cuda.synchronize(dev)
     seconds = max_over_ranks(time.perf_counter() - t0, device=dev, group=group)
     feat = model.input_dim if hasattr(model, "input_dim") else model.encoder.linear.weight.shape[1]
+    if hasattr(model, "saes"):
+        feat = model.saes[0].input_dim
     local_sq = float(sq.item())
     mse = reduce_mse(sq, rows * feat, group=group) if rows or world_size > 1 else float("nan")
     return {"recon_mse": mse, "rows": rows, "batches": batches, "seconds": seconds, "local_sq_err": local_sq,

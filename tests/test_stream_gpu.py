@@ -67,3 +67,33 @@ def test_chunk_stream_one_rank_equals_two_ranks(tmp_path, mode):
     s0, e0 = sharding.shard_rows(len(ds), 2, 0)
     assert doc["rank0_rows"] == e0 - s0 and doc["rank0_batches"] == 3
     assert doc["recon_mse"] == pytest.approx(one["recon_mse"], rel=1e-9)
+
+
+def test_chunk_stream_serves_every_model_class(tmp_path):
+    """stream_reconstruction_error over a small chunk with each module class == the plain loop over the same batches
+    (forward, reconstruction as the reference's adapters pick it, squared error summed in fp64)."""
+    from quantizedsae_amd import (BaselineSparseAutoencoder, QuantizedMatryoshkaSAE, ResidualQuantizedSAE,
+                                  TernarySparseAutoencoder, ops)
+    sys.path.insert(0, str(ROOT / "tools"))
+    import run_chunk_stream as tool
+    chunk = tmp_path / "small.pt"
+    tool.make_chunk(chunk, "gauss", 20)                    # 5000 rows
+    ds = data.HiddenStatesTorchDataset(chunk)
+    tern = TernarySparseAutoencoder(512, 4096)
+    with torch.no_grad():
+        tern.decoder.weight.normal_(0, 0.5)
+    mat = QuantizedMatryoshkaSAE(512, 8192, top_k=32, abs_range=4, n_bits=4)
+    with torch.no_grad():
+        mat.encoder[0].bias.fill_(-0.8)
+    models = [BaselineSparseAutoencoder(512, 8192), tern, mat, ResidualQuantizedSAE(512, 4096, top_k=32, abs_range=1.5, n_bits=4)]
+    for model in models:
+        model = model.to(DEV).eval()
+        got = stream_reconstruction_error(model, [ds], DEV, batch_rows=2048)
+        sq = torch.zeros((), dtype=torch.float64, device=DEV)
+        for xb in ds.iter_batches(2048, DEV):
+            outs = model(xb)
+            rec = outs[-1][-1] if isinstance(outs[-1], (list, tuple)) else outs[-1]
+            ops.sq_err_sum(rec, xb, sq)
+        want = float(sq) / (len(ds) * 512)
+        assert got["rows"] == len(ds) and got["batches"] == 3
+        assert got["recon_mse"] == pytest.approx(want, rel=1e-6), type(model).__name__
