@@ -80,6 +80,16 @@ def test_compiled_forward_returns_the_eager_bits(rows):
         assert same_bits(got2, model(torch.roll(x, 3, 0))), type(model).__name__
 
 
+def test_default_backend_compiles_the_headline_model():
+    """torch.compile(model) with the default backend (inductor): the graph is the one qsae node, nothing for the backend to
+    generate; same bits as eager on the candidate-sweep path."""
+    model = binary_model(H=32768)
+    x = torch.from_numpy(S.activations(95, 4096, 512)).to(DEV)
+    want = model(x)
+    got = torch.compile(model, fullgraph=True)(x)
+    assert same_bits(got, want)
+
+
 def test_compiled_wrapper_call_and_weight_edits():
     """SAEWrapper.__call__ under torch.compile; an in-place weight edit after compilation is seen (the node finds the
     module, whose derived-weight caches are keyed on parameter versions)."""
