@@ -244,8 +244,8 @@ split_dec_bf16_kernel(SdArgs a) {
         issue_dma(i + 1, nxt);
         issue_a(cur, i + 2);                                 // (set `cur` was converted at the end of the previous iteration)
         const char* st = sd_smem + cur * kSdStage;
-        auto k16 = [&](int s) __attribute__((always_inline)) {
-            bf16x8 bf[4], af[2][3];
+        // fragment reads of a k16 group, and its 24 MFMAs (smallest terms first)
+        auto frags = [&](int s, bf16x8 (&bf)[4], bf16x8 (&af)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(st + b_frag + nt * (32 * 64) + choff[s]);
 #pragma unroll
@@ -253,21 +253,27 @@ split_dec_bf16_kernel(SdArgs a) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
                     af[mt][p] = *reinterpret_cast<const bf16x8*>(st + p * kSdPlane + a_frag + mt * (32 * 64) + choff[s]);
+        };
+        auto mfmas = [&](const bf16x8 (&bf)[4], const bf16x8 (&af)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int p = 2; p >= 0; --p)                     // smallest terms first
+            for (int p = 2; p >= 0; --p)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][p], bf[nt], acc[mt][nt], 0, 0, 0);
         };
-        k16(0);
+        bf16x8 bf0[4], af0[2][3], bf1[4], af1[2][3];
+        frags(0, bf0, af0);
+        if constexpr (MODE == 0) frags(1, bf1, af1);         // both groups' reads in flight before the first MFMA (40 more VGPRs:
+                                                             // the matryoshka build has none to spare and reads group 1 later)
+        mfmas(bf0, af0);
         // stage i+1's activations have had most of an iteration to arrive; their split (VALU + three LDS writes per thread,
-        // into the OTHER buffer) sits between the two MFMA groups so that it issues in their shadows instead of holding
-        // every wave of the workgroup in front of the barrier with the matrix pipe idle
+        // into the OTHER buffer) sits between the two MFMA groups: it issues in their shadows
         landed_loop(nxt);
         convert_a(nxt, nxt);
-        k16(1);
+        if constexpr (MODE != 0) frags(1, bf1, af1);
+        mfmas(bf1, af1);
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NA) : "memory");    // dictionary landed, planes written
         __builtin_amdgcn_s_barrier();
     };

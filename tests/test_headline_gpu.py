@@ -169,3 +169,24 @@ def test_baseline_headline_default_path_equals_exact_path_and_oracle():
                                    host(model.decoder.weight), host(model.decoder.bias), k=k)
     assert np.array_equal(host(h[sel]), want["latent"])
     assert np.array_equal(host(recon[sel]), want["reconstruction"])
+
+
+def test_four_times_the_benchmarked_batch():
+    """B = 262144 rows (a 32 GiB dense latent, 2^33 elements: four times the benchmarked batch; sized for the 288 GB of an
+    MI355X): k non-zeros per row, the dense latent is the scatter of the compact outputs, and the two halves of the batch
+    computed separately give the same bits (row independence, 64-bit addressing everywhere)."""
+    model, _ = make_binary(16)
+    big = 4 * B
+    g = torch.Generator(device=DEV)
+    g.manual_seed(17)
+    x = torch.randn((big, D), device=DEV, generator=g)
+    latent, recon, _ = model(x)
+    k = model.top_k
+    assert int((latent != 0).sum()) == big * k
+    idx, val, recon_c = model.forward_compact(x)
+    assert bits_equal(recon_c, recon) and bits_equal(torch.gather(latent, 1, idx.long()), val)
+    del latent
+    half = big // 2
+    i1, v1, r1 = model.forward_compact(x[:half].contiguous())
+    i2, v2, r2 = model.forward_compact(x[half:].contiguous())
+    assert torch.equal(torch.cat([i1, i2]), idx) and bits_equal(torch.cat([v1, v2]), val) and bits_equal(torch.cat([r1, r2]), recon_c)
