@@ -95,6 +95,20 @@ int qsae_encode_dense(const float* x, const float* W, const float* bias, int B, 
 int qsae_encode_dense_kperm(const float* xp, const float* Wp, const float* bias, int B, int D, int H,
                             int act, float* out, int64_t out_ld, qsae_stream_t stream);
 
+/* The same contraction at fp32 ACCURACY, not fp32 bit-exactness, on the fp16 matrix pipe (opt-in; nothing that ranks or
+ * thresholds latents uses it): both operands are split into two fp16 terms under power-of-two scales (x per row, W global),
+ * the three partial contractions x1.w1 + x1.w2 + x2.w1 (every product exact in fp32) run as one fp16 GEMM over a concatenated
+ * K of 3 D with fp32 accumulation.  The result differs from qsae_encode_dense by accumulation-order noise (~1e-6 of a latent's
+ * standard deviation -- the size of the reference's own sgemm-vs-chain difference).  Rows or weights that are not finite give
+ * NaN outputs for the whole row / everything.  D % 64 == 0.
+ *   qsae_emu_pack_w: once per checkpoint, W [H][D] -> Wc (qsae_emu_w_bytes() = 6 H D bytes, opaque), meta2 = 2 device floats;
+ *   qsae_encode_dense_emu: workspace from qsae_encode_dense_emu_workspace_bytes(B, D) (the split copy of the batch). */
+size_t qsae_emu_w_bytes(int H, int D);
+int qsae_emu_pack_w(const float* W, int H, int D, void* Wc, float* meta2, qsae_stream_t stream);
+size_t qsae_encode_dense_emu_workspace_bytes(int B, int D);
+int qsae_encode_dense_emu(const float* x, const void* Wc, const float* meta2, const float* bias, int B, int D, int H, int act,
+                          float* out, int64_t out_ld, void* workspace, size_t workspace_bytes, qsae_stream_t stream);
+
 /* zbits[b][w] bit j = (sigmoid(pre[b][32w+j]) > 0.5) == (pre >= 0x33C00001), pre as above.
  * Replaces encoder(x) followed by `latent > 0.5`, sae/quantized_matryoshka.py:97-99,206-209
  * (also scripts/analysis/dynamic_analysis.py:51).  zbits [B][words_ld] uint32, words_ld >=

@@ -38,6 +38,10 @@ SIGNATURES = {
     "qsae_kperm_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "qsae_encode_dense": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_encode_dense_kperm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "qsae_emu_w_bytes": (_sz, [_i, _i]),
+    "qsae_emu_pack_w": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "qsae_encode_dense_emu_workspace_bytes": (_sz, [_i, _i]),
+    "qsae_encode_dense_emu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
     "qsae_encode_bits": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "qsae_topk_rows": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _i, _vp]),
     "qsae_encode_topk_workspace_bytes": (_sz, [_i, _i, _i, _i]),

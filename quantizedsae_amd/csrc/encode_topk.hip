@@ -1687,6 +1687,125 @@ static int bits_finish(const float* x, const float* W, const float* bias, int B,
     return QSAE_OK;
 }
 
+// ---- fp32-accurate dense encoder on the fp16 matrix pipe (opt-in: HipEncoder.precision = "emulated") -----------------------
+// out = act(bias + x W^T) with BOTH operands split into two fp16 terms under power-of-two scales (x: per row, W: global):
+//   x s_x = x1 + x2 (+ <= 2^-22 |x s_x|),   W s_w = w1 + w2 (+ <= 2^-22 |W s_w|)
+//   x . w  ~  (x1.w1 + x1.w2 + x2.w1) / (s_x s_w)          dropped: x2.w2 and the two remainders, <= 3 2^-22 sum |x_k w_k|
+// Every fp16 x fp16 product is exact in fp32 and the three partial contractions run as ONE fp16 GEMM over a concatenated K:
+// [x1 | x1 | x2] . [w1 | w2 | w1]^T (K' = 3 D), fp32 accumulation.  The result differs from the exact fmaf chain of
+// qsae_encode_dense by fp32 accumulation-order noise (~1e-6 of a latent's standard deviation: the size of the reference's own
+// sgemm-vs-chain difference), so it is NOT bit-identical to the oracle: nothing that ranks or thresholds latents uses it, only
+// the dense ReLU latent of TernarySparseAutoencoder on request.  3 x the fp16 MFMA work of one pass against 16 x the rate.
+__global__ void __launch_bounds__(256)
+emu_w_max_kernel(const float* __restrict__ W, long long n, unsigned* __restrict__ mx_bits) {
+    float mx = 0.f;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * blockDim.x) {
+        const float a = fabsf(W[i]);
+        mx = (a > mx || a != a) ? a : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(mx, off, 64);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(mx_bits, __float_as_uint(mx));       // non-negative floats (and NaN) order like their bits
+}
+
+// Wc[h] = [w1 | w2 | w1] (3 D halves); meta2[0] = s_w (0 when the weights are not finite: every output becomes NaN)
+__global__ void __launch_bounds__(256)
+emu_pack_w_kernel(const float* __restrict__ W, int H, int D, float* __restrict__ meta2, _Float16* __restrict__ Wc) {
+    const float sw = pow2_scale_for(meta2[1]);
+    const long long gid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid == 0) meta2[0] = sw;
+    if (gid >= static_cast<long long>(H) * D) return;
+    const int h = static_cast<int>(gid / D), d = static_cast<int>(gid % D);
+    const float v = W[gid] * sw;                                        // exact scaling
+    const _Float16 w1 = static_cast<_Float16>(v);
+    const _Float16 w2 = static_cast<_Float16>(v - static_cast<float>(w1));       // exact subtraction, one rounding
+    _Float16* row = Wc + static_cast<long long>(h) * 3 * D;
+    row[d] = w1;
+    row[D + d] = w2;
+    row[2 * D + d] = w1;
+}
+
+// one wave per activation row: Xc[b] = [x1 | x1 | x2], inv[b] = 1 / (s_x s_w) (NaN for a row or weights that are not finite)
+__global__ void __launch_bounds__(256)
+emu_x_prep_kernel(const float* __restrict__ x, int B, int D, const float* __restrict__ meta2, _Float16* __restrict__ Xc,
+                  float* __restrict__ inv) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* xr = x + static_cast<long long>(row) * D;
+    float mx = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float a = fabsf(xr[d]);
+        mx = (a > mx || a != a) ? a : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(mx, off, 64);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    const float sx = pow2_scale_for(mx), sw = meta2[0];
+    _Float16* out = Xc + static_cast<long long>(row) * 3 * D;
+    for (int d = lane; d < D; d += 64) {
+        const float v = xr[d] * sx;
+        const _Float16 x1 = static_cast<_Float16>(v);
+        const _Float16 x2 = static_cast<_Float16>(v - static_cast<float>(x1));
+        out[d] = x1;
+        out[D + d] = x1;
+        out[2 * D + d] = x2;
+    }
+    if (lane == 0) inv[row] = (sx > 0.f && sw > 0.f) ? (1.0f / sx) * (1.0f / sw) : __builtin_nanf("");
+}
+
+template <int ACT, int BM, int BN, int WMW, int WNW>
+struct EpiEmuDense {
+    static constexpr int WTM = BM / WMW, WTN = BN / WNW, MT = WTM / 32, NT = WTN / 32;
+    static constexpr int kCheckpoints = 0;
+    static constexpr int kLdsFloats = 0;
+    static constexpr int kStoresPerFinish = 0;
+    struct Args {
+        const float* inv;      // [B]
+        const float* bias;     // [H] or nullptr
+        float* out;            // [B][ld]
+        int64_t ld;
+    };
+    __device__ __forceinline__ void begin(const Args&, const TileCtx&) {}
+    __device__ __forceinline__ void end(const Args&, const TileCtx&) {}
+    __device__ __forceinline__ void init(const Args&, f32x16 (&acc)[MT][NT], const TileCtx&) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    }
+    __device__ __forceinline__ void checkpoint(const Args&, f32x16 (&)[MT][NT], const TileCtx&, int) {}
+    __device__ __forceinline__ void finish(const Args& a, f32x16 (&acc)[MT][NT], const TileCtx& c) {
+        float bcol[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+            bcol[nt] = (a.bias && col < c.N) ? a.bias[col] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c.m0 + c.wm * WTM + mt * 32 + mfma_row(r, c.lane_half);
+                if (row >= c.M) continue;
+                const float iv = a.inv[row];
+                float* orow = a.out + static_cast<int64_t>(row) * a.ld;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = c.n0 + c.wn * WTN + nt * 32 + c.lane_col;
+                    float v = fmaf(acc[mt][nt][r], iv, bcol[nt]);
+                    if (ACT == QSAE_ACT_RELU) v = v > 0.0f ? v : (v != v ? v : 0.0f);      // (NaN stays NaN, like torch.relu)
+                    if (ACT == QSAE_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    if (col < c.N) orow[col] = v;
+                }
+            }
+    }
+};
+
 // ---- dense activations: classify EVERY latent with the fp16 pass, list only the uncertainty band -------------------------------
 // The candidate lists above hold every unit whose approximate latent reaches the cutoff -- all active units.  With dense
 // activations (an untrained encoder: half of the units fire) they overflow and every row falls back to the exact fp32
@@ -2404,4 +2523,64 @@ extern "C" int qsae_encode_bits_band(const float* x, const float* W, const float
     if (flagged_rows) *flagged_rows = nflag;
     if (nflag < 0 || nflag > B) return fail(QSAE_ERR_HIP, "%s: corrupt flagged-row count", __func__);
     return bits_finish(x, W, bias, B, D, H, zbits, words_ld, ws, stream, nflag, kBandCap);
+}
+
+/* fp32-accurate dense encoder on the fp16 matrix pipe (two-term fp16 split of both operands, three partial contractions) */
+extern "C" size_t qsae_emu_w_bytes(int H, int D) {
+    return (H > 0 && D > 0 && D % 64 == 0) ? static_cast<size_t>(H) * 3 * D * 2 : 0;
+}
+
+extern "C" int qsae_emu_pack_w(const float* W, int H, int D, void* Wc, float* meta2, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(H > 0 && D > 0 && W && Wc && meta2, "H > 0, D > 0, non-null pointers");
+    QSAE_CHECK_SUPPORTED(D % 64 == 0, "D must be a multiple of 64");
+    QSAE_CHECK_ARG(aligned16(Wc), "Wc must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    QSAE_HIP(hipMemsetAsync(meta2, 0, 2 * sizeof(float), s));
+    const long long n = static_cast<long long>(H) * D;
+    hipLaunchKernelGGL(emu_w_max_kernel, dim3(1024), dim3(256), 0, s, W, n, reinterpret_cast<unsigned*>(meta2 + 1));
+    QSAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(emu_pack_w_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, W, H, D, meta2,
+                       static_cast<_Float16*>(Wc));
+    QSAE_LAUNCH_CHECK();
+    return QSAE_OK;
+}
+
+extern "C" size_t qsae_encode_dense_emu_workspace_bytes(int B, int D) {
+    if (B <= 0 || D <= 0 || D % 64 != 0) return 0;
+    return align_up(static_cast<size_t>(B) * 3 * D * 2, 256) + align_up(static_cast<size_t>(B) * 4, 256);
+}
+
+extern "C" int qsae_encode_dense_emu(const float* x, const void* Wc, const float* meta2, const float* bias, int B, int D, int H,
+                                     int act, float* out, int64_t out_ld, void* workspace, size_t workspace_bytes,
+                                     qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (B == 0) return QSAE_OK;
+    QSAE_CHECK_ARG(x && Wc && meta2 && out && workspace, "null pointer");
+    QSAE_CHECK_SUPPORTED(D % 64 == 0, "D must be a multiple of 64 (use qsae_encode_dense)");
+    QSAE_CHECK_ARG(act == QSAE_ACT_NONE || act == QSAE_ACT_RELU || act == QSAE_ACT_SIGMOID, "unknown activation");
+    QSAE_CHECK_ARG(out_ld >= H, "out_ld < H");
+    QSAE_CHECK_ARG(aligned16(Wc) && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "Wc 16-byte, workspace 256-byte aligned");
+    QSAE_CHECK_ARG(workspace_bytes >= qsae_encode_dense_emu_workspace_bytes(B, D), "workspace too small");
+    hipStream_t s = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    _Float16* Xc = reinterpret_cast<_Float16*>(ws);
+    float* inv = reinterpret_cast<float*>(ws + align_up(static_cast<size_t>(B) * 3 * D * 2, 256));
+    hipLaunchKernelGGL(emu_x_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, B, D, meta2, Xc, inv);
+    QSAE_LAUNCH_CHECK();
+    const float* xw = reinterpret_cast<const float*>(Xc);
+    const float* ww = reinterpret_cast<const float*>(Wc);
+    const int Kw = 3 * D / 2;
+    if (act == QSAE_ACT_RELU) {
+        using Epi = EpiEmuDense<QSAE_ACT_RELU, 256, 256, 4, 2>;
+        typename Epi::Args ea{inv, bias, out, out_ld};
+        return launch_gemm_dma<Epi, 256, 256, true, 2>(xw, B, ww, H, Kw, ea, s, /*sweep=*/8);
+    }
+    if (act == QSAE_ACT_SIGMOID) {
+        using Epi = EpiEmuDense<QSAE_ACT_SIGMOID, 256, 256, 4, 2>;
+        typename Epi::Args ea{inv, bias, out, out_ld};
+        return launch_gemm_dma<Epi, 256, 256, true, 2>(xw, B, ww, H, Kw, ea, s, /*sweep=*/8);
+    }
+    using Epi = EpiEmuDense<QSAE_ACT_NONE, 256, 256, 4, 2>;
+    typename Epi::Args ea{inv, bias, out, out_ld};
+    return launch_gemm_dma<Epi, 256, 256, true, 2>(xw, B, ww, H, Kw, ea, s, /*sweep=*/8);
 }

@@ -167,6 +167,39 @@ def encode_dense(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def encode_dense_emu_supported(D: int) -> bool:
+    return D > 0 and D % 64 == 0
+
+
+@_on_tensor_device
+def emu_pack_w(W: torch.Tensor):
+    """-> (Wc fp16 [H, 3 D], meta2 fp32 [2]) for encode_dense_emu (once per checkpoint)."""
+    W = _f32c(W, "W")
+    H, D = W.shape
+    Wc = torch.empty((H, 3 * D), dtype=torch.float16, device=W.device)
+    meta2 = torch.zeros((2,), dtype=torch.float32, device=W.device)
+    check(_lib.load().qsae_emu_pack_w(_p(W), H, D, _p(Wc), _p(meta2), _stream()))
+    return Wc, meta2
+
+
+@_on_tensor_device
+def encode_dense_emu(x: torch.Tensor, Wc: torch.Tensor, meta2: torch.Tensor, bias: Optional[torch.Tensor],
+                     act: int = ACT_NONE) -> torch.Tensor:
+    """encode_dense at fp32 accuracy (not bit-exactness) on the fp16 matrix pipe: see qsae_encode_dense_emu."""
+    x = _f32c(x, "x")
+    B, D = x.shape
+    H = Wc.shape[0]
+    b = _f32c(bias, "bias") if bias is not None else None
+    out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    need = int(lib.qsae_encode_dense_emu_workspace_bytes(B, D)) if B > 0 else 1
+    if need == 0:
+        raise ValueError("shape not supported by the emulated encoder (D % 64 == 0)")
+    ws = _workspace(x.device, need)
+    check(lib.qsae_encode_dense_emu(_p(x), _p(Wc), _p(meta2), _p(b), B, D, H, act, _p(out), H, _p(ws), ws.numel(), _stream()))
+    return out
+
+
 @_on_tensor_device
 def encode_bits(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """uint32-packed z bits [B, ceil(H/32)] (returned as int32 tensor)."""

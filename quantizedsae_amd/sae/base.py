@@ -34,8 +34,22 @@ class HipEncoder(nn.Sequential):
     def linear(self) -> nn.Linear:
         return self[0]
 
+    #: "fp32" (default): the exact fmaf chain of the fp32 matrix pipe, bit-identical to the oracle.  "emulated": fp32 ACCURACY
+    #: on the fp16 matrix pipe (both operands as two fp16 terms, three partial contractions, every product exact, fp32
+    #: accumulation; qsae_encode_dense_emu) -- differs from the chain by accumulation-order noise (~1e-6 of a latent's standard
+    #: deviation), about twice as fast.  Only this dense call uses it; the top-k / threshold paths always rank exact latents.
+    precision = "fp32"
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         with torch.no_grad():
+            if self.precision not in ("fp32", "emulated"):
+                raise ValueError(f"precision must be 'fp32' or 'emulated', got {self.precision!r}")
+            W = self[0].weight
+            if self.precision == "emulated" and x.is_cuda and ops.encode_dense_emu_supported(W.shape[1]):
+                if not hasattr(self, "_emu_cache"):
+                    self._emu_cache = PackedCache()
+                st = self._emu_cache.get((W,), lambda: dict(zip(("Wc", "meta2"), ops.emu_pack_w(W.detach()))))
+                return ops.encode_dense_emu(x, st["Wc"], st["meta2"], self[0].bias, self._act)
             xp, Wp, kperm = self.operands(x)
             return ops.encode_dense(xp, Wp, self[0].bias, self._act, kperm=kperm)
 

@@ -68,6 +68,26 @@ def _(x, W, bias, act, kperm):
     return _f32((x.shape[0], W.shape[0]), x)
 
 
+@_op("emu_pack_w")
+def _emu_pack_w(W: Tensor) -> Tuple[Tensor, Tensor]:
+    return _ops.emu_pack_w(W)
+
+
+@_emu_pack_w.register_fake
+def _(W):
+    return torch.empty((W.shape[0], 3 * W.shape[1]), dtype=torch.float16, device=W.device), _f32((2,), W)
+
+
+@_op("encode_dense_emu")
+def _encode_dense_emu(x: Tensor, Wc: Tensor, meta2: Tensor, bias: Optional[Tensor], act: int) -> Tensor:
+    return _ops.encode_dense_emu(x, Wc, meta2, bias, act)
+
+
+@_encode_dense_emu.register_fake
+def _(x, Wc, meta2, bias, act):
+    return _f32((x.shape[0], Wc.shape[0]), x)
+
+
 @_op("encode_bits")
 def _encode_bits(x: Tensor, W: Tensor, bias: Optional[Tensor]) -> Tensor:
     return _ops.encode_bits(x, W, bias)
@@ -440,6 +460,14 @@ def encode_dense(x, W, bias, act=ACT_NONE, out=None, kperm=False):
     return Q.encode_dense(x, W, bias, act, kperm)
 
 
+def emu_pack_w(W):
+    return Q.emu_pack_w(W)
+
+
+def encode_dense_emu(x, Wc, meta2, bias, act=ACT_NONE):
+    return Q.encode_dense_emu(x, Wc, meta2, bias, act)
+
+
 def encode_bits(x, W, bias):
     return Q.encode_bits(x, W, bias)
 
@@ -617,6 +645,7 @@ encode_bits_prefilter_supported = _ops.encode_bits_prefilter_supported
 encode_bits_band_supported = _ops.encode_bits_band_supported
 decode_matryoshka_sparse_supported = _ops.decode_matryoshka_sparse_supported
 split_dec_supported = _ops.split_dec_supported
+encode_dense_emu_supported = _ops.encode_dense_emu_supported
 matryoshka_sizes = _ops.matryoshka_sizes
 binary_row_bytes = _ops.binary_row_bytes
 binary_forward_prefilter_submit = _ops.binary_forward_prefilter_submit

@@ -174,3 +174,49 @@ def test_encode_bits_band_matches_exact(B, Dm, H, shift):
     assert torch.equal(z, want)
     assert 2 <= flagged <= 2 + B // 50                      # the two non-finite rows (+ rows whose band overflows: none expected)
     dens = float(torch.ops.qsae.encode_bits(xd, W, b).view(torch.uint8).to(torch.int32).sum()) if False else None
+
+
+# ---- fp32-accurate encoder on the fp16 matrix pipe (opt-in) -----------------------------------------------------------------
+@pytest.mark.parametrize("B,Dm,H,act", [(300, 512, 4096, 1), (1024, 512, 32768, 0), (257, 128, 1000, 2), (64, 64, 256, 1)])
+def test_emulated_encoder_is_fp32_accurate(B, Dm, H, act):
+    """qsae_encode_dense_emu against the exact fp32 chain (qsae_encode_dense) and an fp64 contraction: two fp16 terms per
+    operand, three partial contractions, every product exact.  It is as far from the fp64 result as the fp32 chain is (a few
+    1e-7 of the latent scale), and within 2e-6 of the chain; rows of very different scale and a non-finite row included."""
+    W = S.xavier_uniform(400, H, Dm, stream=1)
+    b = S.normal(400, (H,), stream=3, std=0.1)
+    x = S.activations(401, B, Dm)
+    x[::5] *= 300.0
+    x[1::5] *= 1e-4
+    Wd, bd, xd = dev(W), dev(b), dev(x)
+    Wc, meta2 = ops.emu_pack_w(Wd)
+    got = host(ops.encode_dense_emu(xd, Wc, meta2, bd, act))
+    f32 = host(ops.encode_dense(xd, Wd, bd, act))
+    pre = x.astype(np.float64) @ W.astype(np.float64).T + b.astype(np.float64)
+    want = np.maximum(pre, 0) if act == 1 else (1 / (1 + np.exp(-pre)) if act == 2 else pre)
+    scale = np.abs(pre).max(axis=1, keepdims=True) + 1e-30            # per row: the rows differ by six orders of magnitude
+    e_emu = (np.abs(got - want) / scale).max()
+    e_f32 = (np.abs(f32 - want) / scale).max()
+    # measured without the row scaling (tools/experiments/r03_emu_err.py): emulated rms 0.7-0.9e-7 / max 1.1e-6 of the row's
+    # largest latent, exact fp32 chain rms 1.1e-7 / max 1.3-1.8e-6 -- the emulation is at least as close to the real numbers
+    assert e_emu < 4e-6 and e_f32 < 4e-6 and e_emu < 1.5 * e_f32 + 2e-7, (e_emu, e_f32)
+    assert (np.abs(got.astype(np.float64) - f32) / scale).max() < 4e-6
+    xb = x.copy()
+    xb[3, 7] = np.nan
+    bad = host(ops.encode_dense_emu(dev(xb), Wc, meta2, bd, act))
+    assert np.isnan(bad[3]).all() and np.array_equal(bad[4], got[4])
+
+
+def test_ternary_model_with_the_emulated_encoder():
+    from quantizedsae_amd import TernarySparseAutoencoder
+    sd = S.ternary_sae_params(410, D, 8192)
+    model = TernarySparseAutoencoder(D, 8192)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    x = S.activations(411, 1000, D)
+    h0, r0 = model(dev(x))
+    want = oracle.ternary_forward(x, sd["encoder.0.weight"], sd["encoder.0.bias"], sd["decoder.weight"])
+    assert np.array_equal(host(h0), want["latent"])                    # default: the exact chain, bit for bit
+    model.encoder.precision = "emulated"
+    h1, r1 = model(dev(x))
+    assert rel_err(host(h1), want["latent"]) < 4e-6 and rel_err(host(r1), want["reconstruction"]) < 1e-5
+    assert not torch.equal(h1, h0)
