@@ -319,6 +319,13 @@ size_t qsae_encode_bits_band_workspace_bytes(int B, int D, int H);
 int qsae_encode_bits_band(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
                           int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
                           size_t workspace_bytes, int* flagged_rows, qsae_stream_t stream);
+/* ... and in two calls (as qsae_encode_bits_prefilter_submit / _finish). */
+int qsae_encode_bits_band_submit(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                 int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                 size_t workspace_bytes, int* flagged_host, qsae_stream_t stream);
+int qsae_encode_bits_band_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                 int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                 size_t workspace_bytes, int flagged, qsae_stream_t stream);
 /* Hidden-major dictionary for the sparse decoder: codes_rows[j][ceil(D/16)] uint32, 2-bit two's-complement
  * fields of S_j/2 (same S as qsae_pack_matryoshka). */
 int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,

@@ -83,6 +83,8 @@ SIGNATURES = {
     "qsae_encode_bits_prefilter_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, _i, _vp]),
     "qsae_encode_bits_band_workspace_bytes": (_sz, [_i, _i, _i]),
     "qsae_encode_bits_band": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, C.POINTER(_i), _vp]),
+    "qsae_encode_bits_band_submit": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, _vp, _vp]),
+    "qsae_encode_bits_band_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp, _sz, _i, _vp]),
     "qsae_pack_matryoshka_rows": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "qsae_decode_matryoshka_sparse": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "qsae_split_dec_supported": (_i, [_i, _i, _i]),

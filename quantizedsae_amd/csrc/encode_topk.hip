@@ -2584,3 +2584,45 @@ extern "C" int qsae_encode_dense_emu(const float* x, const void* Wc, const float
     typename Epi::Args ea{inv, bias, out, out_ld};
     return launch_gemm_dma<Epi, 256, 256, true, 2>(xw, B, ww, H, Kw, ea, s, /*sweep=*/8);
 }
+
+/* the two-call form of qsae_encode_bits_band (see qsae_prefilter_submit / _finish) */
+static int bits_band_args_ok(const char* who, const float* x, const float* W, const void* Wq, const float* meta, int B, int D, int H,
+                             const uint32_t* zbits, int64_t words_ld, const void* workspace, size_t workspace_bytes) {
+    if (!(x && W && Wq && meta && zbits)) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: null pointer", who);
+    if (words_ld < (H + 31) / 32) return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: words_ld < ceil(H/32)", who);
+    if (!bits_band_shape_ok(B, D, H))
+        return fail(QSAE_ERR_UNSUPPORTED, "%s: unsupported: shape not covered (D %% 64 == 0, H %% 32 == 0; use qsae_encode_bits)", who);
+    if (!(aligned16(x) && aligned16(W) && aligned16(Wq)))
+        return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: x, W and Wq must be 16-byte aligned", who);
+    if (!(workspace && workspace_bytes >= bits_layout(B, D, H, kBandCap).total))
+        return fail(QSAE_ERR_WORKSPACE, "%s: workspace too small", who);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
+        return fail(QSAE_ERR_INVALID_ARG, "%s: invalid argument: workspace must be 256-byte aligned", who);
+    return QSAE_OK;
+}
+
+extern "C" int qsae_encode_bits_band_submit(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                            int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                            size_t workspace_bytes, int* flagged_host, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    QSAE_CHECK_ARG(flagged_host != nullptr, "flagged_host must point to a host int");
+    if (B == 0) { *flagged_host = 0; return QSAE_OK; }
+    int rc = bits_band_args_ok(__func__, x, W, Wq, meta, B, D, H, zbits, words_ld, workspace, workspace_bytes);
+    if (rc != QSAE_OK) return rc;
+    char* ws = static_cast<char*>(workspace);
+    rc = bits_band_submit(x, W, bias, static_cast<const _Float16*>(Wq), meta, B, D, H, zbits, words_ld, ws, stream);
+    if (rc != QSAE_OK) return rc;
+    QSAE_HIP(hipMemcpyAsync(flagged_host, ws + bits_layout(B, D, H, kBandCap).flags, sizeof(int), hipMemcpyDeviceToHost,
+                            as_stream(stream)));
+    return QSAE_OK;
+}
+
+extern "C" int qsae_encode_bits_band_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
+                                            int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
+                                            size_t workspace_bytes, int flagged, qsae_stream_t stream) {
+    QSAE_CHECK_ARG(B >= 0 && D > 0 && H > 0, "B >= 0, D > 0, H > 0 required");
+    if (B == 0) return QSAE_OK;
+    const int rc = bits_band_args_ok(__func__, x, W, Wq, meta, B, D, H, zbits, words_ld, workspace, workspace_bytes);
+    if (rc != QSAE_OK) return rc;
+    return bits_finish(x, W, bias, B, D, H, zbits, words_ld, static_cast<char*>(workspace), stream, flagged, kBandCap);
+}

@@ -114,8 +114,8 @@ split_dec_bf16_kernel(SdArgs a) {
         step = step < nsteps ? step : nsteps - 1;    // past the end: the last stage again (into a buffer nobody reads)
         if constexpr (MODE == 0) {
             const char* src = arow + static_cast<long long>(step) * (kSdBK * 4);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(raw[set][0]) : "v"(src));
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(raw[set][1]) : "v"(src));
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(raw[set][0]) : "v"(src));          // (read once: do not displace the dictionary)
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16 nt" : "=&v"(raw[set][1]) : "v"(src));
         } else {
             // scalar base + 32-bit lane offset (the host checks B * words_ld * 4 < 2^32): two registers of addressing
             // instead of four 64-bit pointers

@@ -75,19 +75,34 @@ class SAERegistryEntry:
 
 
 # -- forward adapters: variant outputs -> dicts (framework.py:76-111) ---------------------------
-def _forward_binary(model, batch):
-    latent, reconstruction, polarize_loss = model(batch)
+def _pack_binary(outs):
+    latent, reconstruction, polarize_loss = outs
     return {"latent": latent, "reconstruction": reconstruction, "aux": {"polarize_loss": polarize_loss}}
 
 
-def _forward_levels(model, batch):
-    groups, levels = model(batch)
+def _pack_levels(outs):
+    groups, levels = outs
     return {"latent_groups": groups, "reconstruction_levels": levels, "reconstruction": levels[-1]}
 
 
-def _forward_pair(model, batch):
-    latent, reconstruction = model(batch)
+def _pack_pair(outs):
+    latent, reconstruction = outs
     return {"latent": latent, "reconstruction": reconstruction}
+
+
+def _forward_binary(model, batch):
+    return _pack_binary(model(batch))
+
+
+def _forward_levels(model, batch):
+    return _pack_levels(model(batch))
+
+
+def _forward_pair(model, batch):
+    return _pack_pair(model(batch))
+
+
+_PACKERS = {_forward_binary: _pack_binary, _forward_levels: _pack_levels, _forward_pair: _pack_pair}
 
 
 # -- decoder exports (framework.py:114-162) ------------------------------------------------------
@@ -207,14 +222,39 @@ class SAEWrapper:
 
     @torch.no_grad()
     def reconstruct(self, batch: torch.Tensor) -> torch.Tensor:
+        """The reconstruction only (framework.py:321-323: ``self(batch)["reconstruction"]``).  Models with compact outputs
+        (BinarySAE, Baseline) skip the dense [B, H] latent that nobody asked for here -- same reconstruction bits."""
+        compact = getattr(self.model, "forward_compact", None)
+        if compact is not None:
+            return compact(_ensure_tensor(batch).to(self.device))[2]
         return self(batch)["reconstruction"]
 
     @torch.no_grad()
     def reconstruct_loader(self, dataloader: Iterable[Any], *, return_details: bool = False,
                            ) -> Iterator[Union[torch.Tensor, Dict[str, Any]]]:
+        """One output per batch, in order (framework.py:325-334).  Where the model has the two-call forward, batch i+1 is
+        queued before batch i's outputs are handed out (one batch of look-ahead on the loader): the host round trip of a
+        batch no longer idles the GPU.  Same outputs as calling the wrapper batch by batch."""
+        submit = getattr(self.model, "forward_submit", None)
+        pack = _PACKERS.get(self._entry.forward_adapter)
+        if submit is None or pack is None:
+            for batch in dataloader:
+                outputs = self(batch)
+                yield outputs if return_details else outputs["reconstruction"]
+            return
+        compact = hasattr(self.model, "forward_compact") and not return_details
+        pending, n = None, 0
         for batch in dataloader:
-            outputs = self(batch)
-            yield outputs if return_details else outputs["reconstruction"]
+            batch = _ensure_tensor(batch).to(self.device)
+            handle = submit(batch, slot=n % 2, want_dense=False) if compact else submit(batch, slot=n % 2)
+            n += 1
+            if pending is not None:
+                outs = pending.result()
+                yield outs[2] if compact else (pack(outs) if return_details else pack(outs)["reconstruction"])
+            pending = handle
+        if pending is not None:
+            outs = pending.result()
+            yield outs[2] if compact else (pack(outs) if return_details else pack(outs)["reconstruction"])
 
     def decoder_dictionary(self, **options: Any) -> Dict[str, torch.Tensor]:
         return self._entry.decoder_getter(self.model, options)

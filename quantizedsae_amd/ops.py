@@ -273,15 +273,17 @@ def encode_bits_band(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
 
 @_on_tensor_device
 def encode_bits_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
-                                 meta: torch.Tensor, slot: int = 0) -> "PendingForward":
-    """The two-call form of encode_bits_prefilter (qsae_encode_bits_prefilter_submit / _finish): ``finish()`` returns
-    the z bits; ``flagged_rows`` of the handle is the number of rows that went through the exact dense kernel."""
+                                 meta: torch.Tensor, slot: int = 0, band: bool = False) -> "PendingForward":
+    """The two-call form of encode_bits_prefilter (qsae_encode_bits_prefilter_submit / _finish) or, with ``band``, of
+    encode_bits_band: ``finish()`` returns the z bits; ``flagged_rows`` of the handle is the number of rows that went
+    through the exact dense kernel."""
     x, W = _f32c(x, "x"), _f32c(W, "W")
     B, D = x.shape
     H = W.shape[0]
     b = _f32c(bias, "bias") if bias is not None else None
     lib = _lib.load()
-    need = int(lib.qsae_encode_bits_prefilter_workspace_bytes(B, D, H)) if B > 0 else 1
+    sizer = lib.qsae_encode_bits_band_workspace_bytes if band else lib.qsae_encode_bits_prefilter_workspace_bytes
+    need = int(sizer(B, D, H)) if B > 0 else 1
     if need == 0:
         raise ValueError("shape not supported by the fp16 candidate sweep")
     _claim_slot(x.device, slot)
@@ -289,6 +291,9 @@ def encode_bits_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optiona
     words = (H + 31) // 32
     z = torch.empty((B, words), dtype=torch.int32, device=x.device)
     cargs = (_p(x), _p(W), _p(b), _p(Wq), _p(meta), B, D, H, _p(z), words, _p(ws), ws.numel())
+    if band:
+        return _submit(lib.qsae_encode_bits_band_submit, lib.qsae_encode_bits_band_finish, cargs, (x, W, b, Wq, meta, ws), z,
+                       x.device, slot)
     return _submit(lib.qsae_encode_bits_prefilter_submit, lib.qsae_encode_bits_prefilter_finish, cargs,
                    (x, W, b, Wq, meta, ws), z, x.device, slot)
 

@@ -308,17 +308,18 @@ class QuantizedMatryoshkaSAE(ops.GraphForwardMixin, SparseAutoencoder):
         Batches in flight together need different ``slot`` numbers; models on the dense path compute eagerly."""
         with torch.no_grad():
             xd = require_device_input(x, "x")
-            if self.resolved_bits_path(xd.shape[0]) != "prefilter":
-                return _SubmittedMatryoshka(self, None, self.forward(xd), xd.shape[0])
+            path = self.resolved_bits_path(xd.shape[0])
+            if path not in ("prefilter", "band"):
+                return _SubmittedMatryoshka(self, None, self.forward(xd), xd.shape[0], path)
             W, b = self._encoder_params()
             pw = self._prefilter_weights()
-            pending = ops.encode_bits_prefilter_submit(xd.float(), W, b, pw["Wq"], pw["meta"], slot=slot)
-            return _SubmittedMatryoshka(self, pending, None, xd.shape[0])
+            pending = ops.encode_bits_prefilter_submit(xd.float(), W, b, pw["Wq"], pw["meta"], slot=slot, band=(path == "band"))
+            return _SubmittedMatryoshka(self, pending, None, xd.shape[0], path)
 
 
 class _SubmittedMatryoshka:
-    def __init__(self, model, pending, outs, rows):
-        self._model, self._pending, self._outs, self._rows = model, pending, outs, rows
+    def __init__(self, model, pending, outs, rows, path):
+        self._model, self._pending, self._outs, self._rows, self._path = model, pending, outs, rows, path
 
     def result(self):
         with torch.no_grad():
@@ -327,8 +328,9 @@ class _SubmittedMatryoshka:
                 z = self._pending.finish()
                 flagged = m.last_flagged_rows = self._pending.flagged_rows
                 self._pending = None
-                if flagged * 2 > self._rows:
+                if self._path == "prefilter" and flagged * 2 > self._rows:
                     m._dense_regime = True
                 m.decoder.active_fraction_hint()
-                self._outs = m.decoder.decode_bits(z, sparse=True if flagged * 8 <= self._rows else None)
+                sparse = True if (self._path == "prefilter" and flagged * 8 <= self._rows) else None
+                self._outs = m.decoder.decode_bits(z, sparse=sparse)
             return self._outs

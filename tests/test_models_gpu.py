@@ -534,3 +534,30 @@ def test_baseline_full_size_paths_agree():
                                    host(model.decoder.weight), host(model.decoder.bias), k=model.topk)
     assert np.array_equal(host(h[sel]), want["latent"])
     assert np.array_equal(host(recon[sel]), want["reconstruction"])
+
+
+def test_wrapper_loader_pipelines_large_batches_without_changing_outputs():
+    """SAEWrapper.reconstruct_loader (framework.py:325-334) over several 4096-row batches: the two-call forward runs one batch
+    ahead on the loader; reconstructions, and with return_details the whole dicts, equal the batch-by-batch calls bit for bit;
+    reconstruct() takes the compact path (no dense latent) with the same reconstruction bits."""
+    sd = S.binary_sae_params(120, 512, 8192, 4, 30.0, 0.05, 0.1)
+    model = load(BinarySAE(512, 8192, gamma=4.0, n_bits=4), sd)
+    sae = F.SAEWrapper(F.SAE_REGISTRY["b_sae"], model, DEV)
+    batches = [dev(S.activations(121 + i, 4096, 512)) for i in range(4)] + [dev(S.activations(130, 100, 512))]
+    want = [sae(b) for b in batches]
+    recs = list(sae.reconstruct_loader(batches))
+    assert len(recs) == 5 and all(torch.equal(r, w["reconstruction"]) for r, w in zip(recs, want))
+    dets = list(sae.reconstruct_loader(batches, return_details=True))
+    for d, w in zip(dets, want):
+        assert set(d) == set(w) and torch.equal(d["latent"], w["latent"]) and torch.equal(d["reconstruction"], w["reconstruction"])
+    assert torch.equal(sae.reconstruct(batches[1]), want[1]["reconstruction"])
+    base = F.SAEWrapper(F.SAE_REGISTRY["baseline_sae"], BaselineSparseAutoencoder(512, 8192).to(DEV), DEV)
+    wb = [base(b)["reconstruction"] for b in batches]
+    assert all(torch.equal(r, w) for r, w in zip(base.reconstruct_loader(batches), wb))
+    mat = QuantizedMatryoshkaSAE(512, 8192, top_k=32, abs_range=4, n_bits=4).to(DEV)
+    with torch.no_grad():
+        mat.encoder[0].bias.fill_(-0.8)
+    q = F.SAEWrapper(F.SAE_REGISTRY["q_sae"], mat, DEV)
+    wq = [q(b) for b in batches]
+    for d, w in zip(q.reconstruct_loader(batches, return_details=True), wq):
+        assert all(torch.equal(a, b_) for a, b_ in zip(d["reconstruction_levels"], w["reconstruction_levels"]))

@@ -221,6 +221,16 @@ def test_baseline_and_matryoshka_have_the_two_call_forward():
     sg1, sl1 = h1.result()
     sg2, sl2 = h2.result()
     assert same_bits(sl1, l1) and same_bits(sl2, l2) and same_bits(sg1, g1) and same_bits(sg2, g2)
+    # dense activations: the band classification has the two-call form too
+    with torch.no_grad():
+        mat.encoder[0].bias.fill_(0.0)
+    mat.bits_path = "band"
+    mat.decoder.precision = "fp32"
+    g1, l1 = mat(x1)
+    h1, h2 = mat.forward_submit(x1, slot=0), mat.forward_submit(x2, slot=1)
+    sg1, sl1 = h1.result()
+    h2.result()
+    assert mat.last_flagged_rows == 0 and same_bits(sl1, l1) and same_bits(sg1, g1)
 
 
 def test_sweep_profile_events_are_per_call():
