@@ -706,7 +706,8 @@ def _binary_sae_forward(x: Tensor, params: List[Tensor], handle: int, want_dense
     """BinarySAE.forward / forward_compact: -> (idx, val, dense latent ([0, H] when not wanted), reconstruction, polarize)"""
     m = _module(handle)
     idx, val, latent, recon = m._run(x, want_dense)
-    return idx, val, _dense_or_empty(latent, x, m.hidden_dim), recon, m.decoder.packed()["polarize"]
+    # (the polarize loss is a cached per-checkpoint tensor: an op's outputs have to be fresh tensors, so it is copied)
+    return idx, val, _dense_or_empty(latent, x, m.hidden_dim), recon, m.decoder.packed()["polarize"].clone()
 
 
 @_binary_sae_forward.register_fake
