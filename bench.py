@@ -504,7 +504,11 @@ def main():
             algo_bytes = 2 * B * D + 2 * hswept * D + 4 * B * H + 8 * 320 * B      # x~, W~ (fp16), zeros, ~320 records/row
             gbps = algo_bytes / (enc_ms * 1e-3) / 1e9
             mfma_view = {"bound": "mfma", "what": "fp16 MFMA work of the same launch", "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None}
+                         "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
+                         # static context, not measured by this run: the clock the chip holds under this kernel and the share of
+                         # its cycles the matrix pipes are busy (rocprofv3 --pmc GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES)
+                         "held_clock_ghz_static": 1.71, "mfma_busy_frac_at_held_clock_static": 0.63,
+                         "static_source": "profiles/r03_headline_pmc.txt (tools/r03_headline_pmc.sh)"}
             out["roofline"].update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                     "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_launch": algo_bytes,
                                     "also": mfma_view})
