@@ -273,7 +273,7 @@ def encode_bits_band(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tens
 
 @_on_tensor_device
 def encode_bits_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
-                                 meta: torch.Tensor, slot: int = 0, band: bool = False) -> "PendingForward":
+                                 meta: torch.Tensor, slot: int = 0, band: bool = False, owner: int = 0) -> "PendingForward":
     """The two-call form of encode_bits_prefilter (qsae_encode_bits_prefilter_submit / _finish) or, with ``band``, of
     encode_bits_band: ``finish()`` returns the z bits; ``flagged_rows`` of the handle is the number of rows that went
     through the exact dense kernel."""
@@ -286,6 +286,7 @@ def encode_bits_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optiona
     need = int(sizer(B, D, H)) if B > 0 else 1
     if need == 0:
         raise ValueError("shape not supported by the fp16 candidate sweep")
+    slot = (owner, slot)
     _claim_slot(x.device, slot)
     ws = _workspace(x.device, need, slot, "pending")
     words = (H + 31) // 32
@@ -565,7 +566,7 @@ def _claim_slot(device, slot):
         del _busy_slots[key]                # its handle is gone (collected without finish)
         ref = None
     if ref is not None:
-        raise RuntimeError(f"submit: slot {slot} of this stream still holds a batch whose finish() / result() has not been "
+        raise RuntimeError(f"submit: slot {slot[-1] if isinstance(slot, tuple) else slot} of this stream still holds a batch whose finish() / result() has not been "
                            "called; batches in flight together need different slot numbers")
 
 
@@ -573,10 +574,11 @@ def _claim_slot(device, slot):
 def binary_forward_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
                                     meta: torch.Tensor, k: int, packed: torch.Tensor, n_bits: int, step: float,
                                     dec_bias: Optional[torch.Tensor], want_dense: bool = True,
-                                    slot: int = 0) -> PendingForward:
+                                    slot: int = 0, owner: int = 0) -> PendingForward:
     """The two-call form of binary_forward_prefilter (qsae_prefilter_submit / _finish): nothing in here waits for the
     GPU, so the caller can submit batch i+1 before it finishes batch i.  Batches in flight together on one stream
     need different ``slot`` numbers (each slot is a workspace of its own); finish them in submission order."""
+    slot = (owner, slot)            # slots are per owner (module): two models on one stream do not share workspaces
     _claim_slot(x.device, slot)
     cargs, keep, outs = _decode_prefilter_args(x, W, bias, Wq, meta, k, ("packed", packed, n_bits, step), dec_bias,
                                                want_dense, slot, "pending")
@@ -588,8 +590,9 @@ def binary_forward_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Opti
 def table_forward_prefilter_submit(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], Wq: torch.Tensor,
                                    meta: torch.Tensor, k: int, table: torch.Tensor, scale: float,
                                    dec_bias: Optional[torch.Tensor], want_dense: bool = True,
-                                   slot: int = 0) -> PendingForward:
+                                   slot: int = 0, owner: int = 0) -> PendingForward:
     """The two-call form of table_forward_prefilter (qsae_prefilter_submit_table / _finish_table)."""
+    slot = (owner, slot)
     _claim_slot(x.device, slot)
     cargs, keep, outs = _decode_prefilter_args(x, W, bias, Wq, meta, k, ("table", table, scale), dec_bias, want_dense, slot,
                                                "pending")

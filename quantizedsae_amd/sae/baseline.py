@@ -95,7 +95,7 @@ class BaselineSparseAutoencoder(ops.GraphForwardMixin, nn.Module):
                 xf = xd if (xd.dtype == torch.float32 and xd.is_contiguous()) else xd.float().contiguous()
                 pending = ops.table_forward_prefilter_submit(
                     xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.topk, self._table(), 1.0,
-                    self.decoder.bias.detach(), want_dense=want_dense, slot=slot)
+                    self.decoder.bias.detach(), want_dense=want_dense, slot=slot, owner=self._qsae_handle)
                 return _SubmittedBaseline(self, pending, None, want_dense)
             return _SubmittedBaseline(self, None, self._run(xd, want_dense), want_dense)
 

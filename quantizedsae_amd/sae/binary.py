@@ -296,11 +296,11 @@ class BinarySAE(ops.GraphForwardMixin, SparseAutoencoder):
                 if dec.resolved_decode_mode() == "hard":
                     pending = ops.binary_forward_prefilter_submit(
                         xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.packed()["packed"],
-                        dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot)
+                        dec.n_bits, dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot, owner=self._qsae_handle)
                 else:
                     pending = ops.table_forward_prefilter_submit(
                         xf, lin.weight.detach(), lin.bias.detach(), pw["Wq"], pw["meta"], self.top_k, dec.soft_table(),
-                        dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot)
+                        dec.quantization_step, dec.bias.detach(), want_dense=want_dense, slot=slot, owner=self._qsae_handle)
                 return _SubmittedForward(self, pending, None, want_dense)
             return _SubmittedForward(self, None, self._run(xd, want_dense), want_dense)
 

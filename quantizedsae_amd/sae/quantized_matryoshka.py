@@ -313,7 +313,7 @@ class QuantizedMatryoshkaSAE(ops.GraphForwardMixin, SparseAutoencoder):
                 return _SubmittedMatryoshka(self, None, self.forward(xd), xd.shape[0], path)
             W, b = self._encoder_params()
             pw = self._prefilter_weights()
-            pending = ops.encode_bits_prefilter_submit(xd.float(), W, b, pw["Wq"], pw["meta"], slot=slot, band=(path == "band"))
+            pending = ops.encode_bits_prefilter_submit(xd.float(), W, b, pw["Wq"], pw["meta"], slot=slot, band=(path == "band"), owner=self._qsae_handle)
             return _SubmittedMatryoshka(self, pending, None, xd.shape[0], path)
 
 

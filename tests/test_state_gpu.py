@@ -221,6 +221,9 @@ def test_baseline_and_matryoshka_have_the_two_call_forward():
     sg1, sl1 = h1.result()
     sg2, sl2 = h2.result()
     assert same_bits(sl1, l1) and same_bits(sl2, l2) and same_bits(sg1, g1) and same_bits(sg2, g2)
+    # slots belong to a module: two models with a batch in flight in "slot 0" of the same stream do not collide
+    hb, hm = base.forward_submit(x1, slot=0), mat.forward_submit(x1, slot=0)
+    assert same_bits(hb.result(), w1) and same_bits(hm.result()[1], l1)
     # dense activations: the band classification has the two-call form too
     with torch.no_grad():
         mat.encoder[0].bias.fill_(0.0)
