@@ -40,6 +40,74 @@ __global__ void __launch_bounds__(256) loop_kernel(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// GEMM-like loops on RANDOM data with the A fragments re-read from LDS (conflict-free 16-byte slots per lane) and the B
+// fragments stationary in registers, two waves per SIMD: the candidate sweep's structure (fp16: one W fragment read per
+// 32x32x16 MFMA, or per two 16x16x32 MFMAs) and an fp32 GEMM's (one read per four 32x32x2 / 16x16x4 MFMAs).
+template <int SHAPE>
+__global__ void __launch_bounds__(512) lds_loop_kernel(const float* seed, float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];           // 64 KiB of random bits
+    for (int i = threadIdx.x; i < 16384; i += 512) lds[i] = seed[(blockIdx.x * 16384 + i) & 0xFFFFF];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    f32x4 xb[8];
+    for (int j = 0; j < 8; ++j) xb[j] = *reinterpret_cast<const f32x4*>(lds + ((lane * 4 + 256 * j + 64 * (threadIdx.x >> 6)) & 16380));
+    f32x16 c32[2];
+    f32x4 c16[8];
+    for (int t = 0; t < 2; ++t) for (int e = 0; e < 16; ++e) c32[t][e] = 0.f;
+    for (int t = 0; t < 8; ++t) for (int e = 0; e < 4; ++e) c16[t][e] = 0.f;
+    int off = lane * 4;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + ((off + 256 * j) & 16380));
+            if (SHAPE == 0) {          // fp16 32x32x16: one fragment read per MFMA
+                c32[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, xb[j]), c32[j & 1], 0, 0, 0);
+            } else if (SHAPE == 1) {   // fp16 16x16x32: one fragment read per two MFMAs (two 16-row groups of the stationary operand)
+                c16[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, xb[j]), c16[j & 3], 0, 0, 0);
+                c16[4 + (j & 3)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, xb[j ^ 1]), c16[4 + (j & 3)], 0, 0, 0);
+            } else if (SHAPE == 2) {   // fp32 32x32x2: four MFMAs per fragment read
+#pragma unroll
+                for (int t = 0; t < 4; ++t) c32[j & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], xb[j][t], c32[j & 1], 0, 0, 0);
+            } else {                   // fp32 16x16x4: eight MFMAs per fragment read (same FLOPs per read as above: 2 x half the tile)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    c16[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], xb[j][t], c16[j & 3], 0, 0, 0);
+                    c16[4 + (j & 3)] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], xb[j ^ 1][t], c16[4 + (j & 3)], 0, 0, 0);
+                }
+            }
+        }
+        off += 2048;
+    }
+    float s = 0.f;
+    for (int t = 0; t < 2; ++t) for (int e = 0; e < 16; ++e) s += c32[t][e];
+    for (int t = 0; t < 8; ++t) for (int e = 0; e < 4; ++e) s += c16[t][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int SHAPE>
+static double run_lds(double flop_per_iter_per_wave) {
+    const int iters = 4000, blocks = 256;
+    float *seed, *out;
+    hipMalloc(&seed, (1 << 20) * 4);
+    hipMalloc(&out, blocks * 512 * 4);
+    std::vector<float> h(1 << 20);
+    unsigned s = 99;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (static_cast<int>(s >> 9) % 2001 - 1000) * 1e-3f; }
+    hipMemcpy(seed, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(lds_loop_kernel<SHAPE>, dim3(blocks), dim3(512), 0, 0, seed, out, 100);
+    hipDeviceSynchronize();
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(lds_loop_kernel<SHAPE>, dim3(blocks), dim3(512), 0, 0, seed, out, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    hipFree(seed); hipFree(out);
+    return flop_per_iter_per_wave * iters * blocks * 8.0 / (ms * 1e-3) / 1e12;
+}
+
 // one wave: C[i][j] = sum_k A[i][k] B[k][j], K = 4, through v_mfma_f32_16x16x4_f32 (lane l: row / column l & 15, k = l >> 4)
 __global__ void order_kernel(const float* A, const float* B, float* C, float c0) {
     const int lane = threadIdx.x;
@@ -73,6 +141,8 @@ int main() {
         double tf[6] = {run<0>(w, 32768, 8), run<1>(w, 16384, 32), run<2>(w, 32768, 8), run<3>(w, 16384, 32), run<4>(w, 4096, 8), run<5>(w, 2048, 32)};
         for (int i = 0; i < 6; ++i) printf("%d wave(s)/SIMD  %-14s %8.1f TFLOP/s\n", w, names[i], tf[i]);
     }
+    printf("LDS-fed loops, random data, 2 waves/SIMD:  f16 32x32x16 %.0f TF | f16 16x16x32 %.0f TF | f32 32x32x2 %.1f TF | f32 16x16x4 %.1f TF\n",
+           run_lds<0>(8 * 32768.0), run_lds<1>(16 * 16384.0), run_lds<2>(32 * 4096.0), run_lds<3>(64 * 2048.0));
     // accumulation order of the 16x16x4 fp32 instruction
     std::vector<float> A(64), B(64), C(256);
     unsigned seed = 12345;
