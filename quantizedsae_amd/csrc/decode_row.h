@@ -106,6 +106,78 @@ __device__ __forceinline__ void decode_row_sorted(const int* s_idx, const float*
     }
 }
 
+// The same row decode with up to 64 dictionary rows in flight per lane (the refinement kernel's form for 4- and 8-bit fields:
+// by the time it decodes, the registers of its chain staging are free).  With four rows in flight a row of k = 64 is sixteen
+// dependent round trips to L2 / the memory-side cache -- a third of the refinement's wave time by its phase stamps.  Here lane l
+// holds entry j0 + l of the sorted list, the row addresses are formed on the scalar side (v_readlane -> SGPR base, lane offset in
+// one VGPR), the values enter the fmaf as SGPR operands, and a chunk's 32 + 32 loads are issued before the first is consumed.
+// Padding entries (beyond k) re-read the chunk's first row with value 0: fmaf(0, w, acc) leaves acc as it is (acc is never
+// -0: it starts at +0 and (+0) + (-0) = +0), so the chain is the oracle's, bit for bit.
+template <int FW>
+__device__ __forceinline__ void decode_row_sorted_wide(const int* s_idx, const float* s_val, int k, const RowDecode& d,
+                                                       long long b, int lane) {
+    constexpr int F = 32 / FW;
+    static_assert(F <= 8, "the unrolled chunk is 64 F multiply-adds: fields of 4 bits or more only");
+    for (int c = lane; c < d.row_dwords; c += 64) {
+        float acc[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int jl = j0 + lane;
+            const int myi = s_idx[jl < k ? jl : j0];
+            const float mya = jl < k ? s_val[jl] : 0.0f;
+            const bool two = (k - j0) > 32;                              // wave-uniform
+            uint32_t w0[32], w1[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                w0[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, u)) * d.row_dwords + c];
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    w1[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, 32 + u)) * d.row_dwords + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), u));
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+                    acc[f] = fmaf(a, static_cast<float>(sbfe_i32(static_cast<int>(w0[u]), f * FW, d.n)), acc[f]);
+            }
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), 32 + u));
+#pragma unroll
+                    for (int f = 0; f < F; ++f)
+                        acc[f] = fmaf(a, static_cast<float>(sbfe_i32(static_cast<int>(w1[u]), f * FW, d.n)), acc[f]);
+                }
+            }
+        }
+        float* out = d.recon + b * d.D + c * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int col = c * F + f;
+            if (col < d.D) {
+                float r = d.step * acc[f];          // rounded multiply, then rounded add (binary.py:38)
+                r = r + (d.bias ? d.bias[col] : 0.0f);
+                out[f] = r;
+            }
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void decode_row_sorted_any_wide(const int* s_idx, const float* s_val, int k, const RowDecode& d,
+                                                           long long b, int lane) {
+    if (d.table) { decode_row_table(s_idx, s_val, k, d, b, lane); return; }     // wave-uniform
+    switch (d.fw) {                                  // wave-uniform
+        case 1: decode_row_sorted<1, U>(s_idx, s_val, k, d, b, lane); break;
+        case 2: decode_row_sorted<2, U>(s_idx, s_val, k, d, b, lane); break;
+        case 4: decode_row_sorted_wide<4>(s_idx, s_val, k, d, b, lane); break;
+        default: decode_row_sorted_wide<8>(s_idx, s_val, k, d, b, lane); break;
+    }
+}
+
 template <int U>
 __device__ __forceinline__ void decode_row_sorted_any(const int* s_idx, const float* s_val, int k, const RowDecode& d,
                                                       long long b, int lane) {

@@ -818,6 +818,8 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                    float* __restrict__ dense, int64_t dense_ld, int parts, const int* __restrict__ cnt_parts, RowDecode dec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
     // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
+    // (one workgroup in 64 stamps: with every wave's atomics on the same eight words the stamped launch takes three times as long)
+    if (stamps && (blockIdx.x & 63) != 0) stamps = nullptr;
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     auto stamp = [&](int which) {
         if (stamps) {
@@ -1132,7 +1134,12 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                 s_val[pos[t]] = mine_v[t];
             }
         lds_handoff();
-        decode_row_sorted_any<4>(s_idx, s_val, k, dec, b, lane);    // (eight gathers in flight: 190 VGPRs, two waves per SIMD, slower)
+#ifdef QSAE_AB_NARROW_DECODE
+        decode_row_sorted_any<4>(s_idx, s_val, k, dec, b, lane);
+#else
+        decode_row_sorted_any_wide<4>(s_idx, s_val, k, dec, b, lane);
+#endif
+        stamp(6);
     }
 }
 

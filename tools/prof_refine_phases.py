@@ -25,7 +25,7 @@ ops.encode_topk_prefilter(x, W, bias, Wq, meta, k, want_dense=False)
 torch.cuda.synchronize()
 lib.qsae_debug_set_refine_stamps(None)
 names = ["list load + keys", "bisection", "cut + survivors", "x row -> LDS", "exact chains", "rank + output"]
-s = stamps.cpu().double() / B
+s = stamps.cpu().double() / (B / 64)       # one workgroup in 64 stamps
 for nm, v in zip(names, s.tolist()):
     print(f"{nm:18s} {v:10.0f} cycles/row")
 print(f"{'total':18s} {s.sum().item():10.0f} cycles/row")
