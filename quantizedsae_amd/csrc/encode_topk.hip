@@ -807,6 +807,174 @@ __host__ __device__ static inline size_t ref_lds_per_wave(int) {
     return static_cast<size_t>(kRefMaxSurv) * 8 + 64 * kRefTileStride * 4 + kRefMaxSurv * 4;
 }
 
+// One pass of the exact chains: survivors j0 .. j0 + 63 on lanes 0..63 and, in the two-chain form (kDual), survivors
+// j0 + 64 .. j0 + 64 + nx - 1 (nx <= 8) as a second chain of lanes 0 .. nx - 1.
+// A chain is sequential in k, so one lane owns one survivor; but 64 lanes walking 64 different W rows 16 bytes at a time touch
+// 64 cache lines per load.  Instead the wave fetches [64 survivors x 32 k] blocks line-wise (8 lanes per 128-byte row segment),
+// transposes them through LDS, and every lane then reads its own row's 32 values from there: each W line is fetched once.
+// Two-chain form: a ninth line-load per block fetches the eight extra rows into tile rows 64..71 (kept in the exact-key array
+// behind entry kRefDualKeys, which no survivor of this pass writes before the chains are done); the scalar activation loads, the
+// LDS hand-offs and the gather round trips of the block are shared by both chains.  k = 64 leaves ~69 survivors per row: without
+// this the five beyond the 64th cost a second pass as long as the first.
+constexpr int kRefDualExtra = 8;
+constexpr int kRefDualKeys = 72;     // first exact-key slot the extra tile rows may overlay (this pass writes keys 0..71 only)
+static_assert((kRefMaxSurv - kRefDualKeys) * 8 >= kRefDualExtra * kRefTileStride * 4, "extra tile rows must fit behind the keys");
+static_assert((kRefDualKeys * 8) % 16 == 0, "extra tile rows are read with b128");
+
+template <bool kCounted, int kAbl, bool kDual>
+__device__ __forceinline__ void refine_chain_pass(int j0, int m, int nx, int lane, int* hidx, float* wt, float* wt_x,
+                                                  unsigned long long* ekey, const float* __restrict__ W,
+                                                  const float* __restrict__ bias,
+                                                  const __attribute__((address_space(4))) f32x4* xrow, int D, int ablate,
+                                                  float tau_b, float margin_b) {
+    constexpr int NL = kDual ? 9 : 8;                 // line-loads per block and lane
+    constexpr int kSets = kDual ? 2 : kRefSets;       // W blocks in flight (two-chain form: two sets of nine, the registers of three of eight)
+    auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };
+    const int nblk = D / 32;
+    const int j = j0 + lane;
+    const int h = (j < m) ? hidx[j] : hidx[j0];
+    const int j2 = j0 + 64 + lane;
+    const int h2 = (kDual && lane < nx) ? hidx[j2] : h;
+    float acc = bias ? bias[h] : 0.0f;
+    float acc2 = (kDual && bias) ? bias[h2] : 0.0f;
+    // rows of the line-loads this lane takes part in: rows 8i + lane/8 of the group, as byte offsets into W
+    // (32 bits in the counted form -- the launcher checks 4 H D < 2^32 --, which is also 8 registers less)
+    typename std::conditional<kCounted, uint32_t, int64_t>::type voff[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int jj = j0 + 8 * i + (lane >> 3);
+        jj = (i < 8 ? jj < m : (lane >> 3) < nx) ? jj : j0;
+        // (timing experiments: 1 = eight fixed rows, L1 hits; 7 = every XCD gathers from 1024 rows of its own, L2 hits)
+        const int row = ablate == 1 ? (lane >> 3) : ablate == 7 ? ((hidx[jj] & 1023) | ((blockIdx.x & 7) << 10)) : hidx[jj];
+        if (kCounted) voff[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
+        else voff[i] = static_cast<int64_t>(row) * (D * 4) + 16 * (lane & 7);
+    }
+    const char* wbase = reinterpret_cast<const char*>(W);
+    auto visible_load = [&](f32x4 (&sv)[NL], int blk) {     // loads the compiler sees (and waits for by its own count)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) sv[i] = *reinterpret_cast<const f32x4*>(wbase + voff[i] + 128 * blk);
+    };
+    f32x4 st[kSets][NL];
+    auto consume = [&](const f32x4 (&sv)[NL], int t) {
+        f32x4 xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (kAbl == 3 || kAbl == 6) xv[q] = f32x4{tau_b, margin_b, tau_b, margin_b};
+            else xv[q] = xrow[8 * t + q];
+        }
+        f32x4 w[8];
+        if (kAbl == 4 || kAbl == 6) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = sv[q];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+            if (kDual) *reinterpret_cast<f32x4*>(wt_x + (lane >> 3) * kRefTileStride + 4 * (lane & 7)) = sv[NL - 1];
+            lds_handoff();
+            const float* mine = wt + lane * kRefTileStride;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc = fmaf(xv[q][0], w[q][0], acc);
+            acc = fmaf(xv[q][1], w[q][1], acc);
+            acc = fmaf(xv[q][2], w[q][2], acc);
+            acc = fmaf(xv[q][3], w[q][3], acc);
+        }
+        if (kDual) {
+            if (!(kAbl == 4 || kAbl == 6)) {
+                const float* mine2 = wt_x + (lane & 7) * kRefTileStride;     // lanes >= nx: a valid row, result unused
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine2 + 4 * q);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc2 = fmaf(xv[q][0], w[q][0], acc2);
+                acc2 = fmaf(xv[q][1], w[q][1], acc2);
+                acc2 = fmaf(xv[q][2], w[q][2], acc2);
+                acc2 = fmaf(xv[q][3], w[q][3], acc2);
+            }
+        }
+        lds_handoff();
+    };
+    int t = 0;
+    if (kCounted) {
+        // Counted form (nblk >= 2 kSets).  The compiler's own wait counting gives up on this loop: with the refills
+        // inside it, it puts vmcnt(0) in front of the first block of every round, so each round waits for the set
+        // issued LAST at full latency -- about one set in flight per wave instead of kSets.  Here the loads of
+        // the prologue and of the main loop are inline asm (invisible to that bookkeeping; base in SGPRs, 32-bit
+        // lane offsets) and so are the waits: loads retire in issue order, set q is always followed by exactly
+        // kSets - 1 younger sets, so vmcnt(NL (kSets - 1)) in front of a block means "this set has landed".
+        // The wait statement names the set's registers as read-write operands: every use of the data depends on
+        // it.  The refills are unconditional (main loop: rounds whose refills all exist), so no value defined by an
+        // asm load meets another definition at a join (a copy there would read the register before the data lands).
+        auto issue = [&](f32x4 (&sv)[NL], int blk) {
+            const char* sb = wbase + 128 * blk;             // wave-uniform
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv[i]) : "v"(voff[i]), "s"(sb));
+        };
+        auto landed = [&](f32x4 (&sv)[NL]) {
+            static_assert(kRefSets == 3, "wait counts below");
+            if (kDual)              // two sets of nine
+                asm volatile("s_waitcnt vmcnt(9)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]),
+                             "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]), "+v"(sv[NL - 1]));
+            else                    // three sets of eight
+                asm volatile("s_waitcnt vmcnt(16)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]),
+                             "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
+        };
+        // the loads the compiler does know about (the bias) have to be retired in front of the asm loads: its wait
+        // for them would otherwise sit at the first use inside the loop, as vmcnt(0), in every round
+        asm volatile("" : "+v"(acc), "+v"(acc2));
+#pragma unroll
+        for (int q = 0; q < kSets; ++q) issue(st[q], q);
+        for (; t + 2 * kSets <= nblk; t += kSets) {
+#pragma unroll
+            for (int q = 0; q < kSets; ++q) {
+                if (kAbl != 5) landed(st[q]);
+                consume(st[q], t + q);
+                if (kAbl != 5) issue(st[q], t + q + kSets);
+            }
+        }
+        // everything issued so far has to land before the last rounds (their refills are ordinary loads again)
+#pragma unroll
+        for (int q = 0; q < kSets; ++q) {
+            if (kDual)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[q][0]), "+v"(st[q][1]), "+v"(st[q][2]), "+v"(st[q][3]),
+                             "+v"(st[q][4]), "+v"(st[q][5]), "+v"(st[q][6]), "+v"(st[q][7]), "+v"(st[q][NL - 1]));
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[q][0]), "+v"(st[q][1]), "+v"(st[q][2]), "+v"(st[q][3]),
+                             "+v"(st[q][4]), "+v"(st[q][5]), "+v"(st[q][6]), "+v"(st[q][7]));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kSets; ++q)
+            if (q < nblk) visible_load(st[q], q);
+    }
+    for (; t < nblk; t += kSets) {
+#pragma unroll
+        for (int q = 0; q < kSets; ++q) {
+            if (t + q < nblk) {
+                consume(st[q], t + q);
+                if (t + q + kSets < nblk) visible_load(st[q], t + q + kSets);
+            }
+        }
+    }
+    lds_handoff();
+    if (j < m) {
+        ekey[j] = full_key(acc, static_cast<uint32_t>(h));
+        // keep the exact bits next to the key (NaN payloads / -0 are not recoverable from the key)
+        reinterpret_cast<float*>(hidx)[j] = acc;     // hidx[j] is consumed; reuse the slot for the value
+    }
+    if (kDual && lane < nx) {
+        ekey[j2] = full_key(acc2, static_cast<uint32_t>(h2));
+        reinterpret_cast<float*>(hidx)[j2] = acc2;
+    }
+    lds_handoff();
+}
+
 // kAbl (debug library only, results wrong): 3 = no scalar loads of the activation row, 4 = no LDS transpose, 5 = no
 // gathers in the main loop, 6 = 3 + 4
 template <bool kCounted, int kAbl = 0>
@@ -896,7 +1064,19 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     const uint32_t diff = all_or ^ all_and;
     uint32_t T = all_and & ~(diff ? (0xFFFFFFFFu >> __builtin_clz(diff)) : 0u);   // common prefix
     int at_or_above = n;
-    for (int bit = diff ? 31 - __builtin_clz(diff) : -1; bit >= 0; --bit) {
+    // Only the cut's VALUE matters and only to a fraction of the margin: key bits that move it by less than margin / 8 are
+    // left at 0 (T stays a key with at least k candidates at or above it, so the cut only moves DOWN, by < margin / 8: a few
+    // more survivors at worst, never a missing one).  With positive keys a step of 2^b in the key is 2^b ulps of at most the
+    // largest candidate: b <= exponent(margin) - 3 - (exponent(largest) - 23).  Typically 10 of ~23 bisection rounds go.
+    int lowbit = 0;
+#ifndef QSAE_AB_FULL_BISECT
+    if (all_and & 0x80000000u) {
+        const int e_top = static_cast<int>((all_or >> 23) & 0xFFu), e_m = static_cast<int>((__float_as_uint(margin_b) >> 23) & 0xFFu);
+        lowbit = e_m - e_top + 20;
+        lowbit = lowbit < 0 ? 0 : lowbit > 22 ? 22 : lowbit;
+    }
+#endif
+    for (int bit = diff ? 31 - __builtin_clz(diff) : -1; bit >= lowbit; --bit) {
         if (at_or_above == k) break;
         const uint32_t trial = T | (1u << bit);
         int c = 0;
@@ -944,123 +1124,20 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     // then reads its own row's 32 values from there: each W line is fetched once.
     typedef const __attribute__((address_space(4))) f32x4* cvec_t;
     cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);          // wave-uniform: scalar loads
-    const int nblk = D / 32;
-    for (int j0 = 0; j0 < (ablate == 2 ? 0 : m); j0 += 64) {
-        const int j = j0 + lane;
-        const int h = (j < m) ? hidx[j] : hidx[j0];
-        float acc = bias ? bias[h] : 0.0f;
-        // rows of the 8 line-loads this lane takes part in: rows 8i + lane/8 of the group, as byte offsets into W
-        // (32 bits in the counted form -- the launcher checks 4 H D < 2^32 --, which is also 8 registers less)
-        typename std::conditional<kCounted, uint32_t, int64_t>::type voff[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int jj = j0 + 8 * i + (lane >> 3);
-            jj = jj < m ? jj : j0;
-            // (timing experiments: 1 = eight fixed rows, L1 hits; 7 = every XCD gathers from 1024 rows of its own, L2 hits)
-            const int row = ablate == 1 ? (lane >> 3) : ablate == 7 ? ((hidx[jj] & 1023) | ((blockIdx.x & 7) << 10)) : hidx[jj];
-            if (kCounted) voff[i] = static_cast<uint32_t>(row) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
-            else voff[i] = static_cast<int64_t>(row) * (D * 4) + 16 * (lane & 7);
-        }
-        const char* wbase = reinterpret_cast<const char*>(W);
-        auto visible_load = [&](f32x4 (&sv)[8], int blk) {     // loads the compiler sees (and waits for by its own count)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const f32x4*>(wbase + voff[i] + 128 * blk);
-        };
-        f32x4 st[kRefSets][8];
-        auto consume = [&](const f32x4 (&sv)[8], int t) {
-            f32x4 xv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (kAbl == 3 || kAbl == 6) xv[q] = f32x4{tau_b, margin_b, tau_b, margin_b};
-                else xv[q] = xrow[8 * t + q];
-            }
-            f32x4 w[8];
-            if (kAbl == 4 || kAbl == 6) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) w[q] = sv[q];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
-                lds_handoff();
-                const float* mine = wt + lane * kRefTileStride;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) w[q] = *reinterpret_cast<const f32x4*>(mine + 4 * q);
-                lds_handoff();
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                acc = fmaf(xv[q][0], w[q][0], acc);
-                acc = fmaf(xv[q][1], w[q][1], acc);
-                acc = fmaf(xv[q][2], w[q][2], acc);
-                acc = fmaf(xv[q][3], w[q][3], acc);
-            }
-        };
-        int t = 0;
-        if (kCounted) {
-            // Counted form (nblk >= kRefSets).  The compiler's own wait counting gives up on this loop: with the refills
-            // inside it, it puts vmcnt(0) in front of the first block of every round, so each round waits for the set
-            // issued LAST at full latency -- about one set in flight per wave instead of kRefSets.  Here the loads of
-            // the prologue and of the main loop are inline asm (invisible to that bookkeeping; base in SGPRs, 32-bit
-            // lane offsets) and so are the waits: loads retire in issue order, set q is always followed by exactly
-            // kRefSets - 1 younger sets, so vmcnt(8 (kRefSets - 1)) in front of a block means "this set has landed".
-            // The wait statement names the set's registers as read-write operands: every use of the data depends on
-            // it.  The refills are unconditional (main loop: rounds whose refills all exist), so no value defined by an
-            // asm load meets another definition at a join (a copy there would read the register before the data lands).
-            auto issue = [&](f32x4 (&sv)[8], int blk) {
-                const char* sb = wbase + 128 * blk;             // wave-uniform
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv[i]) : "v"(voff[i]), "s"(sb));
-            };
-            auto landed = [&](f32x4 (&sv)[8]) {
-                static_assert(kRefSets == 2 || kRefSets == 3, "wait counts below");
-                if (kRefSets == 3)
-                    asm volatile("s_waitcnt vmcnt(16)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]),
-                                 "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
-                else
-                    asm volatile("s_waitcnt vmcnt(8)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]),
-                                 "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]));
-            };
-            // the loads the compiler does know about (the bias) have to be retired in front of the asm loads: its wait
-            // for them would otherwise sit at the first use inside the loop, as vmcnt(0), in every round
-            asm volatile("" : "+v"(acc));
-#pragma unroll
-            for (int q = 0; q < kRefSets; ++q) issue(st[q], q);
-            for (; t + 2 * kRefSets <= nblk; t += kRefSets) {
-#pragma unroll
-                for (int q = 0; q < kRefSets; ++q) {
-                    if (kAbl != 5) landed(st[q]);
-                    consume(st[q], t + q);
-                    if (kAbl != 5) issue(st[q], t + q + kRefSets);
-                }
-            }
-            // everything issued so far has to land before the last rounds (their refills are ordinary loads again)
-#pragma unroll
-            for (int q = 0; q < kRefSets; ++q)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[q][0]), "+v"(st[q][1]), "+v"(st[q][2]), "+v"(st[q][3]),
-                             "+v"(st[q][4]), "+v"(st[q][5]), "+v"(st[q][6]), "+v"(st[q][7]));
-        } else {
-#pragma unroll
-            for (int q = 0; q < kRefSets; ++q)
-                if (q < nblk) visible_load(st[q], q);
-        }
-        for (; t < nblk; t += kRefSets) {
-#pragma unroll
-            for (int q = 0; q < kRefSets; ++q) {
-                if (t + q < nblk) {
-                    consume(st[q], t + q);
-                    if (t + q + kRefSets < nblk) visible_load(st[q], t + q + kRefSets);
-                }
-            }
-        }
-        lds_handoff();
-        if (j < m) {
-            ekey[j] = full_key(acc, static_cast<uint32_t>(h));
-            // keep the exact bits next to the key (NaN payloads / -0 are not recoverable from the key)
-            reinterpret_cast<float*>(hidx)[j] = acc;     // hidx[j] is consumed; reuse the slot for the value
-        }
-        lds_handoff();
+    float* wt_x = reinterpret_cast<float*>(ekey + kRefDualKeys);      // tile rows 64..71 of a two-chain pass (see there)
+    for (int j0 = 0; j0 < (ablate == 2 ? 0 : m);) {
+        // a first pass with a short tail behind it (k = 64: ~69 survivors) carries up to eight of the tail's chains as SECOND
+        // chains of lanes 0..7 instead of leaving them a pass of their own
+#ifndef QSAE_AB_NO_DUAL
+        const int nx = (j0 == 0 && m > 64 && D / 32 >= 2 * 2) ? (m - 64 < kRefDualExtra ? m - 64 : kRefDualExtra) : 0;
+#else
+        const int nx = 0;
+#endif
+        if (nx > 0)
+            refine_chain_pass<kCounted, kAbl, true>(j0, m, nx, lane, hidx, wt, wt_x, ekey, W, bias, xrow, D, ablate, tau_b, margin_b);
+        else
+            refine_chain_pass<kCounted, kAbl, false>(j0, m, 0, lane, hidx, wt, wt_x, ekey, W, bias, xrow, D, ablate, tau_b, margin_b);
+        j0 += 64 + nx;
     }
     lds_handoff();
     stamp(4);
