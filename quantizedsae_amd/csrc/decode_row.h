@@ -166,6 +166,85 @@ __device__ __forceinline__ void decode_row_sorted_wide(const int* s_idx, const f
     }
 }
 
+// 4-bit fields holding 4-bit values (n = 4): the same chain with 13 instead of 24 VALU instructions per packed dword.
+// v_cvt_off_f32_i4 turns the low nibble of a byte (SDWA byte select) into nibble / 16 in ONE instruction (no bit-field extract,
+// no integer convert); one shift brings the odd nibbles into that position.  The factor comes back through the other operand:
+// fmaf(16 a, nibble / 16, acc) has the same exact product as fmaf(a, nibble, acc), hence the same rounded sum (16 a is exact
+// unless it overflows: the caller keeps rows with |a| >= 2^123 on the plain form).  Columns 2p, 2p + 1 of a dword share one
+// v_pk_fma_f32 (two independent IEEE fp32 FMAs per instruction).
+typedef float dec_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cvt_off_nibble(uint32_t w, int byte) {        // low nibble of byte `byte`, as signed / 16
+    float r;
+    if (byte == 0) asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(w));
+    else if (byte == 1) asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(w));
+    else if (byte == 2) asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(w));
+    else asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(w));
+    return r;
+}
+
+__device__ __forceinline__ void decode_row_sorted_wide_i4(const int* s_idx, const float* s_val, int k, const RowDecode& d,
+                                                          long long b, int lane) {
+    for (int c = lane; c < d.row_dwords; c += 64) {
+        dec_f32x2 acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = dec_f32x2{0.0f, 0.0f};
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int jl = j0 + lane;
+            const int myi = s_idx[jl < k ? jl : j0];
+            const float mya = jl < k ? 16.0f * s_val[jl] : 0.0f;
+            const bool two = (k - j0) > 32;                              // wave-uniform
+            uint32_t w0[32], w1[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                w0[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, u)) * d.row_dwords + c];
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    w1[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, 32 + u)) * d.row_dwords + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), u));
+                const dec_f32x2 a2 = {a, a};
+                const uint32_t odd = w0[u] >> 4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    acc[p] = __builtin_elementwise_fma(a2, dec_f32x2{cvt_off_nibble(w0[u], p), cvt_off_nibble(odd, p)}, acc[p]);
+            }
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), 32 + u));
+                    const dec_f32x2 a2 = {a, a};
+                    const uint32_t odd = w1[u] >> 4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[p] = __builtin_elementwise_fma(a2, dec_f32x2{cvt_off_nibble(w1[u], p), cvt_off_nibble(odd, p)}, acc[p]);
+                }
+            }
+        }
+        float* out = d.recon + b * d.D + c * 8;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int col = c * 8 + f;
+            if (col < d.D) {
+                float r = d.step * acc[f >> 1][f & 1];          // rounded multiply, then rounded add (binary.py:38)
+                r = r + (d.bias ? d.bias[col] : 0.0f);
+                out[f] = r;
+            }
+        }
+    }
+}
+
+// k winners of one row, 4-bit fields: the 13-instruction form where it is exact (4-bit values, no |a| near overflow), else the plain one
+__device__ __forceinline__ void decode_row_sorted_wide4(const int* s_idx, const float* s_val, int k, const RowDecode& d,
+                                                        long long b, int lane) {
+    bool big = false;
+    for (int j = lane; j < k; j += 64) big |= !(fabsf(s_val[j]) < 0x1p123f);      // (also true for NaN)
+    if (d.n == 4 && !__any(big)) decode_row_sorted_wide_i4(s_idx, s_val, k, d, b, lane);
+    else decode_row_sorted_wide<4>(s_idx, s_val, k, d, b, lane);
+}
+
 template <int U>
 __device__ __forceinline__ void decode_row_sorted_any_wide(const int* s_idx, const float* s_val, int k, const RowDecode& d,
                                                            long long b, int lane) {
@@ -173,7 +252,7 @@ __device__ __forceinline__ void decode_row_sorted_any_wide(const int* s_idx, con
     switch (d.fw) {                                  // wave-uniform
         case 1: decode_row_sorted<1, U>(s_idx, s_val, k, d, b, lane); break;
         case 2: decode_row_sorted<2, U>(s_idx, s_val, k, d, b, lane); break;
-        case 4: decode_row_sorted_wide<4>(s_idx, s_val, k, d, b, lane); break;
+        case 4: decode_row_sorted_wide4(s_idx, s_val, k, d, b, lane); break;
         default: decode_row_sorted_wide<8>(s_idx, s_val, k, d, b, lane); break;
     }
 }

@@ -69,6 +69,11 @@ QSAE_TUNABLE g_fill_co = 1;          // zeros from a co-resident fill kernel on 
 QSAE_TUNABLE g_xstat_rot = 2;        // DMA rotation multiplier (sweep_xstat_f16.h)
 QSAE_TUNABLE_PTR g_ref_stamps = nullptr;     // device buffer [8] for refine phase stamps
 QSAE_TUNABLE g_ref_ablate = 0;       // timing experiments on the refine kernel (results wrong when non-zero)
+#ifdef QSAE_AB_NO_SLICED
+QSAE_TUNABLE g_ref_sliced = 0;
+#else
+QSAE_TUNABLE g_ref_sliced = 1;       // refinement as select / slice-major chains / rank launches: 1 = where it pays (large batches), 0 = never, 2 = wherever the shape allows
+#endif
 QSAE_TUNABLE g_xstat_ablate = 0;     // timing experiments only (results are wrong when non-zero)
 QSAE_TUNABLE g_x_phase = 3;          // experiment: bit 0 = run x prep + sweep (+ fill), bit 1 = run the refinement
 QSAE_TUNABLE g_x_parts = 0;          // experiment: hidden-range parts of the stationary sweep (0 = xstat_parts)
@@ -591,7 +596,7 @@ static int run_fused(const float* x, const float* W, const float* bias, int B, i
 //   exact top-k satisfies s^ >= t~ - 2 eps_b; those survivors (~90 of 32768) are re-evaluated with the
 //   exact chain and ranked exactly.  tests/test_kernels_gpu.py measures max|s^ - s| / eps_b on hardware.
 struct PrefLayout {
-    size_t xq, inv, margin, cnt_parts, total_extra;
+    size_t xq, inv, margin, cnt_parts, sl_offs, total_extra;
 };
 static PrefLayout pref_layout(int B, int D, size_t base) {
     PrefLayout P;
@@ -600,6 +605,7 @@ static PrefLayout pref_layout(int B, int D, size_t base) {
     P.inv = off;    off = align_up(off + static_cast<size_t>(B) * 4, 256);
     P.margin = off; off = align_up(off + static_cast<size_t>(B) * 4, 256);
     P.cnt_parts = off; off = align_up(off + static_cast<size_t>(B) * 4 * 7, 256);    // list-segment counters of parts 1..7
+    P.sl_offs = off; off = align_up(off + static_cast<size_t>(B) * 65, 256);        // sliced refinement: survivors below slice s, [S + 1][B] bytes (kSlMaxSlices + 1 rows)
     P.total_extra = off;
     return P;
 }
@@ -975,41 +981,14 @@ __device__ __forceinline__ void refine_chain_pass(int j0, int m, int nx, int lan
     lds_handoff();
 }
 
-// kAbl (debug library only, results wrong): 3 = no scalar loads of the activation row, 4 = no LDS transpose, 5 = no
-// gathers in the main loop, 6 = 3 + 4
-template <bool kCounted, int kAbl = 0>
-__global__ void __launch_bounds__(64 * kRefWaves, 3)            // three workgroups per CU: <= 168 registers
-refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
-                   const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
-                   const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
-                   float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps,
-                   float* __restrict__ dense, int64_t dense_ld, int parts, const int* __restrict__ cnt_parts, RowDecode dec) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
-    // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
-    // (one workgroup in 64 stamps: with every wave's atomics on the same eight words the stamped launch takes three times as long)
-    if (stamps && (blockIdx.x & 63) != 0) stamps = nullptr;
-    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    auto stamp = [&](int which) {
-        if (stamps) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[which], t - tprev);
-            tprev = t;
-        }
-    };
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x * kRefWaves + wave;                       // wave-uniform
-    if (b >= B) return;
-    unsigned char* mybase = ref_smem + static_cast<size_t>(wave) * ref_lds_per_wave(D);
-    unsigned long long* ekey = reinterpret_cast<unsigned long long*>(mybase);
-    float* wt = reinterpret_cast<float*>(mybase + kRefMaxSurv * 8);
-    int* hidx = reinterpret_cast<int*>(wt + 64 * kRefTileStride);
-    auto flag_row = [&]() {
-        if (lane == 0) {
-            const int slot = atomicAdd(&flags[0], 1);
-            flags[1 + slot] = b;
-        }
-    };
+// Front half of the refinement of one row (one wave): the row's candidate list -> LDS, the approximate k-th largest value, the
+// cut, the survivors' hidden indices into hidx[0 .. m) (list order).  Returns m, or -1 if the row was handed to the exact kernels
+// (flag_row called).  `wt` is the wave's W-tile space (>= 2 kCandCap words), used for the staged list.
+template <class FlagFn, class StampFn>
+__device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap,
+                                                 const float* __restrict__ tau, const float* __restrict__ margin, int B, int H, int k,
+                                                 int parts, const int* __restrict__ cnt_parts, int b, int lane, float* wt, int* hidx,
+                                                 FlagFn flag_row, StampFn stamp, float& tau_b_out, float& margin_b_out) {
     auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };       // in-order LDS queue: compiler barrier only
     // row scalars through the constant address space (written by earlier launches only): s_load, no VGPRs
     typedef const __attribute__((address_space(4))) int* cint_t;
@@ -1025,7 +1004,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     }
     const float tau_b = ((cflt_t)tau)[b];
     const float margin_b = ((cflt_t)margin)[b];
-    if (n < k || seg_overflow) { flag_row(); return; }
+    if (n < k || seg_overflow) { flag_row(); return -1; }
     // ---- candidate list -> LDS (the W tile's space: value keys [1024] | hidden indices [1024]) ----------
     // Keys live in LDS, not in 16 register slots per lane: short loops instead of 4000 lines of unrolled
     // select code, and the registers go to the W staging sets.
@@ -1053,7 +1032,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         filled += np;
     }
     if (n + lane < nslots * 64) lkey[n + lane] = 0u;                   // padding of the last slot
-    if (__any(any_nan)) { flag_row(); return; }                        // NaN latents: let the exact path rank them
+    if (__any(any_nan)) { flag_row(); return -1; }                        // NaN latents: let the exact path rank them
     lds_handoff();
     stamp(0);
     // ---- approximate k-th largest VALUE: MSB-first bisection below the highest differing bit -------------
@@ -1098,7 +1077,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     // key -> value (inverse of mono_key on non-NaN keys)
     const float tk = __uint_as_float((tkey & 0x80000000u) ? (tkey & 0x7FFFFFFFu) : ~tkey);
     // the list holds everything >= tau - margin; t~ must not lie below tau or survivors could be missing
-    if (!(tk >= tau_b)) { flag_row(); return; }
+    if (!(tk >= tau_b)) { flag_row(); return -1; }
     const uint32_t cutkey = mono_key(tk - margin_b);                   // keep <=> !(value < cut) <=> key >= cutkey
     // ---- survivors -> LDS ----------------------------------------------------------------------------
     int m = 0;
@@ -1113,35 +1092,22 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
         }
         m += __popcll(msk);
     }
-    if (m > kRefMaxSurv) { flag_row(); return; }
-    lds_handoff();
-    stamp(2);
-    stamp(3);
-    // ---- exact fp32 chain per survivor (ascending k, seeded with the bias: the oracle's arithmetic) ---
-    // A chain is sequential in k, so one lane owns one survivor; but 64 lanes walking 64 different W rows
-    // 16 bytes at a time touch 64 cache lines per load.  Instead the wave fetches [64 survivors x 32 k]
-    // blocks line-wise (8 lanes per 128-byte row segment), transposes them through LDS, and every lane
-    // then reads its own row's 32 values from there: each W line is fetched once.
-    typedef const __attribute__((address_space(4))) f32x4* cvec_t;
-    cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);          // wave-uniform: scalar loads
-    float* wt_x = reinterpret_cast<float*>(ekey + kRefDualKeys);      // tile rows 64..71 of a two-chain pass (see there)
-    for (int j0 = 0; j0 < (ablate == 2 ? 0 : m);) {
-        // a first pass with a short tail behind it (k = 64: ~69 survivors) carries up to eight of the tail's chains as SECOND
-        // chains of lanes 0..7 instead of leaving them a pass of their own
-#ifndef QSAE_AB_NO_DUAL
-        const int nx = (j0 == 0 && m > 64 && D / 32 >= 2 * 2) ? (m - 64 < kRefDualExtra ? m - 64 : kRefDualExtra) : 0;
-#else
-        const int nx = 0;
-#endif
-        if (nx > 0)
-            refine_chain_pass<kCounted, kAbl, true>(j0, m, nx, lane, hidx, wt, wt_x, ekey, W, bias, xrow, D, ablate, tau_b, margin_b);
-        else
-            refine_chain_pass<kCounted, kAbl, false>(j0, m, 0, lane, hidx, wt, wt_x, ekey, W, bias, xrow, D, ablate, tau_b, margin_b);
-        j0 += 64 + nx;
-    }
-    lds_handoff();
-    stamp(4);
-    if (ablate == 2) return;           // (timing experiment without the chains: the keys below were never written -- no outputs)
+    if (m > kRefMaxSurv) { flag_row(); return -1; }
+    tau_b_out = tau_b;
+    margin_b_out = margin_b;
+    return m;
+}
+
+// Back half: exact keys ekey[0 .. m) and exact values (as floats in hidx[0 .. m)) -> exact rank, the k winners to idx / val / the
+// dense latent, and the row's reconstruction when a decoder is attached.  `wt` (the W tile's space) and `ekey` are reused.
+// kDecode (what the launch's decoder can be, so that the rank launch carries one decoder's registers, not all of them):
+// 0 any (dispatch at run time), 1 packed 4-bit fields, 2 packed 8-bit fields, 3 none
+template <int kDecode = 0, class StampFn>
+__device__ __forceinline__ void refine_rank_decode(unsigned long long* ekey, int* hidx, float* wt, int m, int k, int b, int lane,
+                                                   int32_t* __restrict__ idx_out, float* __restrict__ val_out,
+                                                   float* __restrict__ dense, int64_t dense_ld, int* __restrict__ flags,
+                                                   const RowDecode& dec, StampFn stamp) {
+    auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };
     // ---- exact rank among the survivors ----------------------------------------------------------------
     // (with a decoder attached the winners are also kept in LDS, in the W tile's space, which is free by now)
     int* w_idx = reinterpret_cast<int*>(wt);
@@ -1153,14 +1119,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     // written by then are exact values of true members of the top-k (a duplicate displaces one, it adds none), which the
     // exact kernels write again.
     bool twice = false;
-    for (int j = lane; j < m; j += 64) {
-        const unsigned long long mine = ekey[j];
-        int rank = 0, same = 0;
-        for (int i = 0; i < m; ++i) {
-            const unsigned long long other = ekey[i];
-            rank += (other > mine) ? 1 : 0;
-            same += (other == mine) ? 1 : 0;
-        }
+    auto emit = [&](int j, unsigned long long mine, int rank, int same) {
         twice |= same != 1;
         if (rank < k) {
             const int32_t hi = static_cast<int32_t>(key_index(mine));
@@ -1172,6 +1131,41 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
                 w_idx[rank] = hi;
                 w_val[rank] = vv;
             }
+        }
+    };
+    if (m <= 128) {
+        // the usual case (k = 64: ~69 survivors): both of a lane's keys are ranked by ONE walk over the keys (one broadcast
+        // LDS read per key serves both)
+        const int j1 = 64 + lane;
+        const unsigned long long mine0 = lane < m ? ekey[lane] : 0ull, mine1 = j1 < m ? ekey[j1] : 0ull;
+        int rank0 = 0, same0 = 0, rank1 = 0, same1 = 0;
+        if (m <= 64) {
+            for (int i = 0; i < m; ++i) {
+                const unsigned long long other = ekey[i];
+                rank0 += (other > mine0) ? 1 : 0;
+                same0 += (other == mine0) ? 1 : 0;
+            }
+        } else {
+            for (int i = 0; i < m; ++i) {
+                const unsigned long long other = ekey[i];
+                rank0 += (other > mine0) ? 1 : 0;
+                same0 += (other == mine0) ? 1 : 0;
+                rank1 += (other > mine1) ? 1 : 0;
+                same1 += (other == mine1) ? 1 : 0;
+            }
+        }
+        if (lane < m) emit(lane, mine0, rank0, same0);
+        if (j1 < m) emit(j1, mine1, rank1, same1);
+    } else {
+        for (int j = lane; j < m; j += 64) {
+            const unsigned long long mine = ekey[j];
+            int rank = 0, same = 0;
+            for (int i = 0; i < m; ++i) {
+                const unsigned long long other = ekey[i];
+                rank += (other > mine) ? 1 : 0;
+                same += (other == mine) ? 1 : 0;
+            }
+            emit(j, mine, rank, same);
         }
     }
     if (__any(twice)) {
@@ -1185,7 +1179,7 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
     // ---- sparse decode of this row (BinarySAE): winners into ascending index order, then the fmaf chain over the
     // k dictionary rows.  Same code as the stand-alone decode kernel; here its gathers and integer converts run in
     // the issue slots the other waves' chain gathers leave idle.
-    if (dec.active()) {
+    if (kDecode != 3 && dec.active()) {
         lds_handoff();
         int* s_idx = reinterpret_cast<int*>(ekey);                       // the exact keys are no longer needed
         float* s_val = reinterpret_cast<float*>(ekey) + kRefMaxSurv;
@@ -1214,10 +1208,440 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
 #ifdef QSAE_AB_NARROW_DECODE
         decode_row_sorted_any<4>(s_idx, s_val, k, dec, b, lane);
 #else
-        decode_row_sorted_any_wide<4>(s_idx, s_val, k, dec, b, lane);
+        if (kDecode == 1) decode_row_sorted_wide4(s_idx, s_val, k, dec, b, lane);
+        else if (kDecode == 2) decode_row_sorted_wide<8>(s_idx, s_val, k, dec, b, lane);
+        else decode_row_sorted_any_wide<4>(s_idx, s_val, k, dec, b, lane);
 #endif
         stamp(6);
     }
+}
+
+// kAbl (debug library only, results wrong): 3 = no scalar loads of the activation row, 4 = no LDS transpose, 5 = no
+// gathers in the main loop, 6 = 3 + 4
+template <bool kCounted, int kAbl = 0>
+__global__ void __launch_bounds__(64 * kRefWaves, 3)            // three workgroups per CU: <= 168 registers
+refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
+                   const float* __restrict__ margin, const float* __restrict__ x, const float* __restrict__ W,
+                   const float* __restrict__ bias, int B, int D, int H, int k, int32_t* __restrict__ idx_out,
+                   float* __restrict__ val_out, int* __restrict__ flags, int ablate, unsigned long long* __restrict__ stamps,
+                   float* __restrict__ dense, int64_t dense_ld, int parts, const int* __restrict__ cnt_parts, RowDecode dec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ref_smem[];
+    // debug: per-phase cycle totals over all waves (stamps == nullptr in normal operation)
+    // (one workgroup in 64 stamps: with every wave's atomics on the same eight words the stamped launch takes three times as long)
+    if (stamps && (blockIdx.x & 63) != 0) stamps = nullptr;
+    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int which) {
+        if (stamps) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[which], t - tprev);
+            tprev = t;
+        }
+    };
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kRefWaves + wave;                       // wave-uniform
+    if (b >= B) return;
+    unsigned char* mybase = ref_smem + static_cast<size_t>(wave) * ref_lds_per_wave(D);
+    unsigned long long* ekey = reinterpret_cast<unsigned long long*>(mybase);
+    float* wt = reinterpret_cast<float*>(mybase + kRefMaxSurv * 8);
+    int* hidx = reinterpret_cast<int*>(wt + 64 * kRefTileStride);
+    auto flag_row = [&]() {
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+    };
+    auto lds_handoff = [&]() { asm volatile("" ::: "memory"); };       // in-order LDS queue: compiler barrier only
+    float tau_b, margin_b;
+    const int m = refine_select_row(cand, cnt, cap, tau, margin, B, H, k, parts, cnt_parts, b, lane, wt, hidx, flag_row, stamp, tau_b,
+                                    margin_b);
+    if (m < 0) return;
+    lds_handoff();
+    stamp(2);
+    stamp(3);
+    // ---- exact fp32 chain per survivor (ascending k, seeded with the bias: the oracle's arithmetic) ---
+    // A chain is sequential in k, so one lane owns one survivor; but 64 lanes walking 64 different W rows
+    // 16 bytes at a time touch 64 cache lines per load.  Instead the wave fetches [64 survivors x 32 k]
+    // blocks line-wise (8 lanes per 128-byte row segment), transposes them through LDS, and every lane
+    // then reads its own row's 32 values from there: each W line is fetched once.
+    typedef const __attribute__((address_space(4))) f32x4* cvec_t;
+    cvec_t xrow = (cvec_t)(x + static_cast<int64_t>(b) * D);          // wave-uniform: scalar loads
+    float* wt_x = reinterpret_cast<float*>(ekey + kRefDualKeys);      // tile rows 64..71 of a two-chain pass (see there)
+    for (int j0 = 0; j0 < (ablate == 2 ? 0 : m);) {
+        // a first pass with a short tail behind it (k = 64: ~69 survivors) carries up to eight of the tail's chains as SECOND
+        // chains of lanes 0..7 instead of leaving them a pass of their own
+#ifndef QSAE_AB_NO_DUAL
+        const int nx = (j0 == 0 && m > 64 && D / 32 >= 2 * 2) ? (m - 64 < kRefDualExtra ? m - 64 : kRefDualExtra) : 0;
+#else
+        const int nx = 0;
+#endif
+        if (nx > 0)
+            refine_chain_pass<kCounted, kAbl, true>(j0, m, nx, lane, hidx, wt, wt_x, ekey, W, bias, xrow, D, ablate, tau_b, margin_b);
+        else
+            refine_chain_pass<kCounted, kAbl, false>(j0, m, 0, lane, hidx, wt, wt_x, ekey, W, bias, xrow, D, ablate, tau_b, margin_b);
+        j0 += 64 + nx;
+    }
+    lds_handoff();
+    stamp(4);
+    if (ablate == 2) return;           // (timing experiment without the chains: the keys below were never written -- no outputs)
+    refine_rank_decode(ekey, hidx, wt, m, k, b, lane, idx_out, val_out, dense, dense_ld, flags, dec, stamp);
+}
+
+// ---- the refinement regrouped by hidden slice: select -> slice-major chains -> rank / decode ------------------------
+// The one-launch refinement above is bound by the rate at which the fabric delivers W rows: 69 survivors x 2 KiB per
+// activation row, 64 MiB of W against 4 MiB of L2 per XCD, 25 % hits.  Here the exact chains run
+// SLICE-MAJOR instead: the hidden units are cut into S slices of <= 4 MiB of W, XCD x owns slices x, x + 8, ..., and
+// works through all rows' survivors of one slice before it touches the next, so a slice is fetched from the fabric once per
+// XCD and every later gather of it is an L2 hit.  Three launches:
+//   1. refine_select_kernel (one wave per row): list -> approximate k-th -> survivors (refine_select_row), sorted by hidden
+//      index into the row's own candidate segment (the list is in LDS by then), plus offs[s][b] = number of the row's
+//      survivors below slice s (one byte each, slice-major so that the chain kernel reads them coalesced).
+//   2. refine_slice_chain_kernel: wave task = (slice, 128 rows).  The rows' entries of that slice are expanded into a queue
+//      of (row, entry) pairs and taken 64 at a time, one chain per lane.  W rows AND activation rows are fetched line-wise
+//      (8 lanes per 128-byte segment) and transposed through LDS; a lane reads its W row and its activation row (shared
+//      with the neighbouring lanes of the same row) from there.  Same fmaf chain, ascending k, seeded with the bias: the
+//      values are bit-identical to the row-major kernel's.  They go behind the sorted list in the row's segment.
+//   3. refine_rank_kernel (one wave per row): exact keys from (value, index), rank, outputs, row decode (refine_rank_decode).
+// The activation rows are re-read once per slice (S x 128 MiB, mostly L2 / memory-side-cache hits) in exchange for ~7 GB of
+// W misses.  Prototype (tools/experiments/r03_slice_chain.hip, chains only, 69 survivors per row): S = 8 | 16 | 32:
+// 0.84 | 0.76 | 0.82 ms, bound by the LDS traffic of the two transpositions (26 KiB per 64 pairs x 32 k).
+constexpr int kSlList = 256;           // ints per row for the sorted survivor list; the exact values follow as kSlList floats
+constexpr int kSlMaxSlices = 64;
+constexpr int kSlRowsPerWave = 128;
+constexpr int kSlXRows = 40;           // distinct activation rows per batch of 64 pairs (more: the batch is cut short)
+constexpr int kSlQueue = 640;          // (row, entry) pairs per expansion round
+constexpr int kSlicedMinRows = 16384;  // below this a slice's share of the rows does not fill the chip
+static_assert(kSlList * 8 <= kCandCap * 8, "sorted list + values must fit the row's candidate segment");
+constexpr int kSlSelectLds = 2 * kCandCap * 4 + kRefMaxSurv * 4;                                  // per wave
+constexpr int kSlChainLds = 64 * kRefTileStride * 4 + kSlXRows * kRefTileStride * 4 + kSlQueue * 4 + 64 * 4;
+constexpr int kSlRankLds = kRefMaxSurv * 8 + 2 * kRefMaxSurv * 4 + kRefMaxSurv * 4;
+
+__global__ void __launch_bounds__(64 * kRefWaves)
+refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
+                     const float* __restrict__ margin, int B, int H, int k, int parts, const int* __restrict__ cnt_parts,
+                     int* __restrict__ flags, int S, int per_shift, uint8_t* __restrict__ offs /* [S + 1][B] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sel_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kRefWaves + wave;
+    if (b >= B) return;
+    float* wt = reinterpret_cast<float*>(sel_smem + static_cast<size_t>(wave) * kSlSelectLds);
+    int* hidx = reinterpret_cast<int*>(wt + 2 * kCandCap);
+    auto flag_row = [&]() {
+        if (lane == 0) {
+            const int slot = atomicAdd(&flags[0], 1);
+            flags[1 + slot] = b;
+        }
+    };
+    auto no_stamp = [](int) {};
+    auto no_survivors = [&]() {                                        // a flagged row has nothing for the next two launches
+        for (int s = lane; s <= S; s += 64) offs[static_cast<size_t>(s) * B + b] = 0;
+    };
+    float tau_b, margin_b;
+    int m = refine_select_row(cand, cnt, cap, tau, margin, B, H, k, parts, cnt_parts, b, lane, wt, hidx, flag_row, no_stamp, tau_b,
+                              margin_b);
+    if (m > 255) { flag_row(); m = -1; }                               // (offsets are bytes)
+    if (m < 0) { no_survivors(); return; }
+    asm volatile("" ::: "memory");
+    // ---- the list by slice.  The sweep appends a row's candidates stage by stage (64 hidden units each, ascending), so the
+    // survivors normally arrive with their slices already in ascending runs and are stored as they are; if not (lists from
+    // another producer, parts out of order), they are sorted by hidden index first.
+    const int nsl = (m + 63) / 64;
+    int mine[4];
+    bool unordered = false;
+    int last_slice = 0;                                                // slice of the entry in front of this slot (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = 64 * t + lane;
+        mine[t] = 0x7FFFFFFF;
+        if (t < nsl) {
+            if (j < m) mine[t] = hidx[j];
+            const int sl = mine[t] >> per_shift;                       // (unused lanes: far beyond the last slice)
+            int before = __shfl_up(sl, 1, 64);
+            before = lane == 0 ? last_slice : before;
+            unordered |= j < m && sl < before;
+            last_slice = __builtin_amdgcn_readlane(sl, 63);
+        }
+    }
+    int* list = reinterpret_cast<int*>(cand + static_cast<int64_t>(b) * cap);      // every entry of the segment has been read by now
+    if (!__any(unordered)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < nsl && 64 * t + lane < m) list[64 * t + lane] = mine[t];
+    } else {
+        int pos[4];
+        bool twice = false;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pos[t] = -1;
+            if (t < nsl && 64 * t + lane < m) {
+                int below = 0, same = 0;
+                for (int i = 0; i < m; ++i) {
+                    const int o = hidx[i];
+                    below += (o < mine[t]) ? 1 : 0;
+                    same += (o == mine[t]) ? 1 : 0;
+                }
+                pos[t] = below;
+                twice |= same != 1;
+            }
+        }
+        if (__any(twice)) { flag_row(); no_survivors(); return; }     // a unit listed twice: positions collide
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (pos[t] >= 0) list[pos[t]] = mine[t];
+    }
+    const int per = 1 << per_shift;
+    int myoff = 0;
+    for (int s = 1; s < S; ++s) {
+        const int lim = s * per;
+        int c = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < nsl) c += __popcll(__ballot(mine[t] < lim));        // (unused slots hold INT_MAX)
+        if (lane == s) myoff = c;
+    }
+    if (lane < S) offs[static_cast<size_t>(lane) * B + b] = static_cast<uint8_t>(myoff);
+    if (lane == 0) offs[static_cast<size_t>(S) * B + b] = static_cast<uint8_t>(m);
+}
+
+// one batch of <= 64 (row, entry) pairs: lane l runs the chain of pair l; NXL = line-loads per block for the activation rows
+template <int NXL>
+__device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                  uint2* __restrict__ cand, int cap, int D, int row0, uint32_t my, bool valid, int lane,
+                                                  float* wt, float* xt, const int* xr, int R, int rx) {
+    const int b = row0 + static_cast<int>(my >> 8), ent = static_cast<int>(my & 255u);
+    int* list = reinterpret_cast<int*>(cand + static_cast<int64_t>(b) * cap);
+    const int h = list[ent];
+    float acc = bias ? bias[h] : 0.0f;
+    uint32_t woff[8], xoff[NXL];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        woff[i] = static_cast<uint32_t>(__shfl(h, 8 * i + (lane >> 3), 64)) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+        int tr = 8 * i + (lane >> 3);
+        tr = tr < R ? tr : R - 1;
+        xoff[i] = static_cast<uint32_t>(xr[tr]) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
+    }
+    const char* wb = reinterpret_cast<const char*>(W);
+    const char* xb = reinterpret_cast<const char*>(x);
+    const int nblk = D / 32;
+    constexpr int NL = 8 + NXL;                        // line-loads per block and lane
+    constexpr int kSets = NXL <= 2 ? 3 : 2;            // blocks in flight
+    f32x4 st[kSets][NL];
+    auto visible_load = [&](f32x4 (&sv)[NL], int blk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const f32x4*>(wb + woff[i] + 128 * blk);
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) sv[8 + i] = *reinterpret_cast<const f32x4*>(xb + xoff[i] + 128 * blk);
+    };
+    auto consume = [&](const f32x4 (&sv)[NL]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+#pragma unroll
+        for (int i = 0; i < NXL; ++i)
+            *reinterpret_cast<f32x4*>(xt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[8 + i];
+        asm volatile("" ::: "memory");
+        const float* mw = wt + lane * kRefTileStride;
+        const float* mx = xt + rx * kRefTileStride;
+        f32x4 w[8], xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            w[q] = *reinterpret_cast<const f32x4*>(mw + 4 * q);
+            xv[q] = *reinterpret_cast<const f32x4*>(mx + 4 * q);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc = fmaf(xv[q][0], w[q][0], acc);
+            acc = fmaf(xv[q][1], w[q][1], acc);
+            acc = fmaf(xv[q][2], w[q][2], acc);
+            acc = fmaf(xv[q][3], w[q][3], acc);
+        }
+    };
+    // counted waits as in refine_chain_pass: asm loads (SGPR base, 32-bit lane offsets), loads retire in issue order, a set is
+    // always followed by kSets - 1 younger ones, so vmcnt(NL (kSets - 1)) means "this set has landed"
+    auto issue = [&](f32x4 (&sv)[NL], int blk) {
+        const char* sw = wb + 128 * blk;                // wave-uniform
+        const char* sx = xb + 128 * blk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv[i]) : "v"(woff[i]), "s"(sw));
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv[8 + i]) : "v"(xoff[i]), "s"(sx));
+    };
+    auto landed = [&](f32x4 (&sv)[NL]) {
+#define QSAE_SL_REGS8 "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7])
+        if (NXL == 1) asm volatile("s_waitcnt vmcnt(18)" : QSAE_SL_REGS8, "+v"(sv[8]));                                           // 2 x 9
+        else if (NXL == 2) asm volatile("s_waitcnt vmcnt(20)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[NL - 1]));                    // 2 x 10
+        else if (NXL == 4) asm volatile("s_waitcnt vmcnt(12)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[NL - 1]));
+        else asm volatile("s_waitcnt vmcnt(13)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[NL - 1]));
+    };
+    auto all_landed = [&](f32x4 (&sv)[NL]) {
+        if (NXL == 1) asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]));
+        else if (NXL == 2) asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[NL - 1]));
+        else if (NXL == 4) asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[NL - 1]));
+        else asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[NL - 1]));
+#undef QSAE_SL_REGS8
+    };
+    static_assert(NXL == 1 || NXL == 2 || NXL == 4 || NXL == 5, "wait counts above");
+    int t = 0;
+    if (nblk >= kSets) {
+        asm volatile("" : "+v"(acc));                   // the loads the compiler knows about (list entry, bias) retire first
+#pragma unroll
+        for (int q = 0; q < kSets; ++q) issue(st[q], q);
+        for (; t + 2 * kSets <= nblk; t += kSets) {
+#pragma unroll
+            for (int q = 0; q < kSets; ++q) {
+                landed(st[q]);
+                consume(st[q]);
+                issue(st[q], t + q + kSets);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kSets; ++q) all_landed(st[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < kSets; ++q)
+            if (q < nblk) visible_load(st[q], q);
+    }
+    for (; t < nblk; t += kSets) {
+#pragma unroll
+        for (int q = 0; q < kSets; ++q) {
+            if (t + q < nblk) {
+                consume(st[q]);
+                if (t + q + kSets < nblk) visible_load(st[q], t + q + kSets);
+            }
+        }
+    }
+    if (valid) reinterpret_cast<float*>(list)[kSlList + ent] = acc;
+}
+static_assert(kSlXRows == 40, "slice_chain_batch<5> fills exactly 40 tile rows");
+
+__global__ void __launch_bounds__(64 * kRefWaves, 2)
+refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                          uint2* __restrict__ cand, int cap, const uint8_t* __restrict__ offs, int B, int D, int S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* base = chain_smem + static_cast<size_t>(wave) * kSlChainLds;
+    float* wt = reinterpret_cast<float*>(base);
+    float* xt = wt + 64 * kRefTileStride;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(xt + kSlXRows * kRefTileStride);
+    int* xr = reinterpret_cast<int*>(queue + kSlQueue);
+    // workgroup g runs on XCD g mod 8 (round-robin dispatch); XCD x owns slices x, x + 8, ... and takes them one after the other
+    const int g = blockIdx.x, xcd = g & 7, q = g >> 3;
+    const int wgs_per_slice = (B + kSlRowsPerWave * kRefWaves - 1) / (kSlRowsPerWave * kRefWaves);
+    const int slice = xcd + 8 * (q / wgs_per_slice);
+    if (slice >= S) return;
+    const int row0 = ((q % wgs_per_slice) * kRefWaves + wave) * kSlRowsPerWave;
+    if (row0 >= B) return;
+    int at[2], left[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int r = row0 + 64 * half + lane;
+        at[half] = 0;
+        left[half] = 0;
+        if (r < B) {
+            at[half] = offs[static_cast<size_t>(slice) * B + r];
+            left[half] = static_cast<int>(offs[static_cast<size_t>(slice + 1) * B + r]) - at[half];
+        }
+    }
+    while (__any(left[0] > 0 || left[1] > 0)) {
+        // ---- expand the rows' entries of this slice into the queue (as many rounds as it takes) ----
+        int total = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c = left[half];
+            int incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            const int start = total + incl - c;
+            int wrote = 0;
+            for (int i = 0; i < c; ++i)
+                if (start + i < kSlQueue) {
+                    queue[start + i] = (static_cast<uint32_t>(64 * half + lane) << 8) | static_cast<uint32_t>(at[half] + i);
+                    ++wrote;
+                }
+            at[half] += wrote;
+            left[half] -= wrote;
+            total += __shfl(incl, 63, 64);
+        }
+        total = total < kSlQueue ? total : kSlQueue;
+        asm volatile("" ::: "memory");
+        // ---- batches of up to 64 pairs, cut short where the activation tile would overflow ----
+        int p0 = 0;
+        while (p0 < total) {
+            const int p = p0 + lane;
+            const bool in = p < total;
+            const uint32_t my = queue[in ? p : p0];
+            const int rl = static_cast<int>(my >> 8);
+            const int prev = __shfl_up(rl, 1, 64);
+            const bool head = in && (lane == 0 || prev != rl);
+            const unsigned long long hb = __ballot(head);
+            int rx = __popcll(hb & ((2ull << lane) - 1ull)) - 1;      // tile row of this lane's activation row
+            const unsigned long long over = __ballot(in && rx >= kSlXRows);
+            const int take = over ? __builtin_ctzll(over) : (total - p0 < 64 ? total - p0 : 64);
+            const bool valid = lane < take;
+            const int R = __popcll(hb & (take >= 64 ? ~0ull : ((1ull << take) - 1ull)));
+            if (head && valid) xr[rx] = row0 + rl;
+            rx = valid ? rx : 0;
+            asm volatile("" ::: "memory");
+            if (R <= 8) slice_chain_batch<1>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
+            else if (R <= 16) slice_chain_batch<2>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
+            else if (R <= 32) slice_chain_batch<4>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
+            else slice_chain_batch<5>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
+            asm volatile("" ::: "memory");
+            p0 += take;
+        }
+    }
+}
+
+template <int kDecode>
+__global__ void __launch_bounds__(64 * kRefWaves, kDecode == 0 ? 3 : 4)
+refine_rank_kernel(const uint2* __restrict__ cand, int cap, const uint8_t* __restrict__ offs, int S, int B, int k,
+                   int32_t* __restrict__ idx_out, float* __restrict__ val_out, int* __restrict__ flags, float* __restrict__ dense,
+                   int64_t dense_ld, RowDecode dec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rank_smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * kRefWaves + wave;
+    if (b >= B) return;
+    const int m = offs[static_cast<size_t>(S) * B + b];
+    if (m == 0) return;                                                // flagged by the select launch
+    unsigned char* mybase = rank_smem + static_cast<size_t>(wave) * kSlRankLds;
+    unsigned long long* ekey = reinterpret_cast<unsigned long long*>(mybase);
+    float* wt = reinterpret_cast<float*>(mybase + kRefMaxSurv * 8);     // winners (2 kRefMaxSurv words)
+    int* hval = reinterpret_cast<int*>(wt + 2 * kRefMaxSurv);
+    const int* list = reinterpret_cast<const int*>(cand + static_cast<int64_t>(b) * cap);
+    for (int j = lane; j < m; j += 64) {
+        const int h = list[j];
+        const float v = reinterpret_cast<const float*>(list)[kSlList + j];
+        ekey[j] = full_key(v, static_cast<uint32_t>(h));
+        reinterpret_cast<float*>(hval)[j] = v;
+    }
+    asm volatile("" ::: "memory");
+    auto no_stamp = [](int) {};
+    refine_rank_decode<kDecode>(ekey, hval, wt, m, k, b, lane, idx_out, val_out, dense, dense_ld, flags, dec, no_stamp);
+}
+
+// slices of 2^shift hidden units, at most 4 MiB of W each; their number a multiple of 8 (one per XCD and round; slices past H
+// are empty).  false: more than kSlMaxSlices would be needed.
+static bool sliced_plan(int H, int D, int* S, int* shift) {
+    int sh = 0;
+    while ((static_cast<size_t>(2) << sh) * D * 4 <= (4u << 20)) ++sh;              // largest 2^sh with 2^sh D 4 <= 4 MiB
+    int n = (H + (1 << sh) - 1) >> sh;
+    n = (n + 7) / 8 * 8;
+    *S = n;
+    *shift = sh;
+    return n <= kSlMaxSlices;
+}
+
+static bool sliced_fits(int H, int D) {
+    int S, sh;
+    return sliced_plan(H, D, &S, &sh);
 }
 
 // Zero-fill of the dense latent by a kernel that runs BESIDE the sweep.  Carried by the sweep's own waves the 8.4 M
@@ -1435,7 +1859,32 @@ static int prefilter_submit(const PrefCall& c) {
         if (xstat && g_xstat_ablate != 0) return QSAE_OK;    // timing experiment: the lists are not trustworthy
     }
     // 5. survivors -> exact chain -> exact top-k (-> the row's reconstruction)
-    if (g_x_phase & 2) {
+    const bool sliced = g_ref_sliced != 0 && g_ref_ablate == 0 && g_ref_stamps == nullptr && D % 32 == 0 && D / 32 >= 2 &&
+                        static_cast<uint64_t>(H) * D * 4 < (1ull << 32) && static_cast<uint64_t>(B) * D * 4 < (1ull << 32) &&
+                        (g_ref_sliced == 2 || B >= kSlicedMinRows) && sliced_fits(H, D);
+    if ((g_x_phase & 2) && sliced) {
+        // 5'. the same refinement as three launches, chains slice-major (see refine_select_kernel)
+        int S = 0, per_shift = 0;
+        sliced_plan(H, D, &S, &per_shift);
+        uint8_t* offs = reinterpret_cast<uint8_t*>(ws + PL.sl_offs);
+        QSAE_SET_MAX_LDS_ONCE(refine_select_kernel, 160 * 1024);
+        QSAE_SET_MAX_LDS_ONCE(refine_slice_chain_kernel, 160 * 1024);
+        const dim3 rows_grid((B + kRefWaves - 1) / kRefWaves), block(64 * kRefWaves);
+        hipLaunchKernelGGL(refine_select_kernel, rows_grid, block, kSlSelectLds * kRefWaves, s, cand, cnt, kCandCap, tau, margin, B, H, k,
+                           parts, cnt_parts, flags, S, per_shift, offs);
+        QSAE_LAUNCH_CHECK();
+        const int wgs_per_slice = (B + kSlRowsPerWave * kRefWaves - 1) / (kSlRowsPerWave * kRefWaves);
+        hipLaunchKernelGGL(refine_slice_chain_kernel, dim3(8 * (S / 8) * wgs_per_slice), block, kSlChainLds * kRefWaves, s, c.x, c.W,
+                           c.bias, cand, kCandCap, offs, B, D, S);
+        QSAE_LAUNCH_CHECK();
+        const RowDecode rd = c.dec ? *c.dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr};
+        auto rank = refine_rank_kernel<0>;
+        if (!rd.active()) rank = refine_rank_kernel<3>;
+        else if (rd.packed && !rd.table && rd.fw == 4) rank = refine_rank_kernel<1>;
+        else if (rd.packed && !rd.table && rd.fw == 8) rank = refine_rank_kernel<2>;
+        hipLaunchKernelGGL(rank, rows_grid, block, kSlRankLds * kRefWaves, s, cand, kCandCap, offs, S, B, k, c.idx, c.val, flags,
+                           pl.filled, c.dense_ld, rd);
+    } else if (g_x_phase & 2) {
         const size_t lds = ref_lds_per_wave(D) * kRefWaves;
         // counted-wait form of the chains: at least kRefSets blocks of 32 per row, W addressable with 32-bit offsets
         const bool counted = D / 32 >= kRefSets && static_cast<uint64_t>(H) * D * 4 < (1ull << 32);
@@ -2175,6 +2624,11 @@ extern "C" int qsae_debug_set_xstat_stamps(void* buf) {
 
 extern "C" int qsae_debug_set_refine_stamps(void* buf) {
     g_ref_stamps = static_cast<unsigned long long*>(buf);
+    return QSAE_OK;
+}
+
+extern "C" int qsae_debug_set_refine_sliced(int v) {
+    g_ref_sliced = v;
     return QSAE_OK;
 }
 
