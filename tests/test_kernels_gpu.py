@@ -770,3 +770,128 @@ def test_ablation_builds_of_the_encoder_run_clean_at_the_shape_that_once_faulted
             assert f(x.data_ptr(), W.data_ptr(), B, D, H, out.data_ptr(), 2, ablate, stream) == 0
             torch.cuda.synchronize()
     assert torch.equal(out, want)                              # the last build run (0) is the complete pipeline
+
+
+# ---- refinement as three launches, chains slice-major (large batches by default; forced here on small shapes) ----------
+@pytest.fixture
+def sliced_refinement(fused_path):
+    lib = fused_path
+    lib.qsae_debug_set_refine_sliced.argtypes = [C.c_int]
+    lib.qsae_debug_set_refine_sliced(2)
+    try:
+        yield lib
+    finally:
+        lib.qsae_debug_set_refine_sliced(1)
+
+
+@pytest.mark.parametrize("B,D,H,k", [(1000, 512, 8192, 65), (300, 64, 4096, 8), (2100, 512, 32768, 65), (515, 256, 16384, 32),
+                                     (700, 1024, 8192, 64), (129, 64, 4100, 3), (640, 512, 8192, 130)])
+def test_sliced_refinement_equals_oracle_and_the_one_launch_form(sliced_refinement, B, D, H, k):
+    """select / slice-major chains / rank == the oracle's top-k, and bit for bit the one-launch refinement; rows not a
+    multiple of the 128-row wave tasks, one to many slices (H D 4 / 4 MiB rounded to eight), k on both sides of 64."""
+    ops = _ops()
+    lib = sliced_refinement
+    x = S.activations(195, B, D)
+    W = S.xavier_uniform(195, H, D, stream=1)
+    bias = S.normal(195, (H,), stream=3, std=0.05)
+    assert ops.prefilter_supported(B, D, H, k)
+    info = {}
+    idx, val, dense = _prefilter(ops, x, W, bias, k, info=info)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+    assert np.array_equal(host(dense), oracle.densify(want_idx, want_val, H))
+    lib.qsae_debug_set_refine_sliced(0)
+    info0 = {}
+    idx0, val0, dense0 = _prefilter(ops, x, W, bias, k, info=info0)
+    lib.qsae_debug_set_refine_sliced(2)
+    assert torch.equal(idx, idx0) and torch.equal(val.view(torch.int32), val0.view(torch.int32)) and torch.equal(dense, dense0)
+    assert info["flagged_rows"] == info0["flagged_rows"]
+    idx2, val2, none = _prefilter(ops, x, W, None, k, want_dense=False)
+    w2 = oracle.topk(oracle.encode(x, W, None), k)
+    assert none is None and np.array_equal(host(idx2), w2[0]) and np.array_equal(host(val2), w2[1])
+
+
+@pytest.mark.parametrize("n_bits", [4, 8, 2, 0])
+def test_sliced_refinement_decodes_like_the_one_launch_form(sliced_refinement, n_bits):
+    """The rank launch's row decode -- packed 4-bit fields (the 13-instruction nibble form), 8-bit fields, narrower fields
+    (generic form), an fp32 table (n_bits 0) -- against the one-launch refinement and the stand-alone decode kernel;
+    degenerate rows (all ties, NaN, inf) take the exact kernels in both forms."""
+    ops = _ops()
+    lib = sliced_refinement
+    B, D, H, k = 1100, 512, 8192, 65
+    x = S.activations(196, B, D)
+    x[5] = 0.0
+    x[17, 3] = np.nan
+    x[40, 100] = np.inf
+    W = S.xavier_uniform(196, H, D, stream=1)
+    bias = S.normal(196, (H,), stream=3, std=0.05)
+    dbias = dev(S.normal(196, (D,), stream=5, std=0.1))
+    xd, Wd, bd = dev(x), dev(W), dev(bias)
+    Wq, meta = ops.prefilter_pack_w(Wd, bd)
+    if n_bits:
+        logits = dev(S.normal(196, (H, D * n_bits), stream=7, std=30.0))
+        packed, _ = ops.pack_binary(logits, D, n_bits)
+        call = lambda: ops.binary_forward_prefilter(xd, Wd, bd, Wq, meta, k, packed, n_bits, 0.25, dbias)
+    else:
+        table = dev(S.normal(196, (H, D), stream=7, std=1.0))
+        call = lambda: ops.table_forward_prefilter(xd, Wd, bd, Wq, meta, k, table, 0.5, dbias)
+    got = call()
+    lib.qsae_debug_set_refine_sliced(0)
+    want = call()
+    lib.qsae_debug_set_refine_sliced(2)
+    for a, b_ in zip(got, want):
+        assert torch.equal(a.view(torch.int32), b_.view(torch.int32))
+    if n_bits:
+        rec = ops.decode_binary_sparse(got[0], got[1], packed, D, n_bits, 0.25, dbias)
+        ok = np.ones(B, bool); ok[[17, 40]] = False
+        assert np.array_equal(host(rec)[ok], host(got[3])[ok])
+
+
+def test_sliced_refinement_sorts_lists_that_are_not_in_slice_order(sliced_refinement):
+    """The select launch stores the survivors as they come when their slices already form ascending runs (the sweep's order)
+    and sorts them otherwise; a unit listed twice or an index outside the dictionary still hands the row to the exact
+    kernels.  The lists are edited between the two halves of a call (debug build)."""
+    ops = _ops()
+    lib = sliced_refinement
+    lib.qsae_debug_set_phases.argtypes = [C.c_int, C.c_int]
+    B, D, H, k = 520, 512, 32768, 65                      # 16 slices of 2048 units
+    x = S.activations(197, B, D)
+    W = S.xavier_uniform(197, H, D, stream=1)
+    bias = S.normal(197, (H,), stream=3, std=0.1)
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    offs = [C.c_size_t() for _ in range(5)]
+    cap, parts = C.c_int(), C.c_int()
+    lib.qsae_debug_prefilter_list_offsets.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 5 + [C.POINTER(C.c_int)] * 2
+    lib.qsae_debug_prefilter_list_offsets(B, D, H, k, *[C.byref(o) for o in offs], C.byref(cap), C.byref(parts))
+    cand_off, cnt_off, cntp_off = offs[0].value, offs[1].value, offs[2].value
+    P, cap_part = parts.value, cap.value // parts.value   # small batches: the hidden range in P parts, one list segment each
+    try:
+        lib.qsae_debug_set_phases(1, 0)
+        _prefilter(ops, x, W, bias, k, want_dense=False)
+        torch.cuda.synchronize()
+        ws = ops._workspace(torch.device(DEV), 1)
+        cand = ws[cand_off: cand_off + B * cap.value * 8].view(torch.int32).reshape(B, cap.value, 2)
+        cnt = np.zeros((P, B), np.int64)
+        cnt[0] = host(ws[cnt_off: cnt_off + B * 4].view(torch.int32))
+        if P > 1:
+            cnt[1:] = host(ws[cntp_off: cntp_off + (P - 1) * B * 4].view(torch.int32)).reshape(P - 1, B)
+        assert (cnt.sum(0) >= k).all() and (cnt <= cap_part).all() and (cnt[0, 300:311] >= 2).all()
+        g = torch.Generator().manual_seed(5)
+        for b in range(0, 300):                            # rows 0-199: every segment back to front (descending slices inside
+            for p_ in range(P):                            # a part); rows 200-299: every segment in a random order
+                n, lo = int(cnt[p_, b]), p_ * cap_part
+                order = torch.arange(n - 1, -1, -1) if b < 200 else torch.randperm(n, generator=g)
+                cand[b, lo:lo + n] = cand[b, lo:lo + n][order.to(cand.device)]
+        top = torch.from_numpy(np.stack([want_val[300:310, 0].view(np.int32), want_idx[300:310, 0].astype(np.int32)], axis=1)).to(cand.device)
+        cand[300:310, 0, :] = top                          # rows 300-309: the best unit listed twice
+        cand[300:310, 1, :] = top
+        cand[310, 0, 1] = H + 5
+        info = {}
+        lib.qsae_debug_set_phases(2, 0)
+        idx, val, _ = _prefilter(ops, x, W, bias, k, want_dense=False, info=info)
+    finally:
+        lib.qsae_debug_set_phases(3, 0)
+    assert 11 <= info["flagged_rows"] < 40
+    assert np.array_equal(host(idx), want_idx)
+    assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
