@@ -192,36 +192,30 @@ __device__ __forceinline__ void decode_row_sorted_wide_i4(const int* s_idx, cons
             const int jl = j0 + lane;
             const int myi = s_idx[jl < k ? jl : j0];
             const float mya = jl < k ? 16.0f * s_val[jl] : 0.0f;
-            const bool two = (k - j0) > 32;                              // wave-uniform
-            uint32_t w0[32], w1[32];
+            const int rem = k - j0;                                      // wave-uniform; entries of this chunk: min(rem, 64)
+            // eight groups of eight entries, each behind a wave-uniform guard (k = 65 leaves one entry for the second chunk:
+            // one group, not 32 padded entries); all loads of the chunk are issued before the first is consumed
+            uint32_t w[64];
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                w0[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, u)) * d.row_dwords + c];
-            if (two) {
+            for (int g = 0; g < 8; ++g)
+                if (rem > 8 * g) {
 #pragma unroll
-                for (int u = 0; u < 32; ++u)
-                    w1[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, 32 + u)) * d.row_dwords + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), u));
-                const dec_f32x2 a2 = {a, a};
-                const uint32_t odd = w0[u] >> 4;
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    acc[p] = __builtin_elementwise_fma(a2, dec_f32x2{cvt_off_nibble(w0[u], p), cvt_off_nibble(odd, p)}, acc[p]);
-            }
-            if (two) {
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), 32 + u));
-                    const dec_f32x2 a2 = {a, a};
-                    const uint32_t odd = w1[u] >> 4;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        acc[p] = __builtin_elementwise_fma(a2, dec_f32x2{cvt_off_nibble(w1[u], p), cvt_off_nibble(odd, p)}, acc[p]);
+                    for (int u = 8 * g; u < 8 * g + 8; ++u)
+                        w[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, u)) * d.row_dwords + c];
                 }
-            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (rem > 8 * g) {
+#pragma unroll
+                    for (int u = 8 * g; u < 8 * g + 8; ++u) {
+                        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), u));
+                        const dec_f32x2 a2 = {a, a};
+                        const uint32_t odd = w[u] >> 4;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            acc[p] = __builtin_elementwise_fma(a2, dec_f32x2{cvt_off_nibble(w[u], p), cvt_off_nibble(odd, p)}, acc[p]);
+                    }
+                }
         }
         float* out = d.recon + b * d.D + c * 8;
 #pragma unroll

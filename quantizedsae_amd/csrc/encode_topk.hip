@@ -1011,7 +1011,8 @@ __device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand,
     const uint2* list = cand + static_cast<int64_t>(b) * cap;
     const int nslots = (n + 63) / 64;                                  // wave-uniform
     uint32_t* lkey = reinterpret_cast<uint32_t*>(wt);                  // 0 = no candidate (mono keys are >= 0x007FFFFF)
-    uint32_t* lidx = lkey + kCandCap;
+    uint16_t* lidx = reinterpret_cast<uint16_t*>(lkey + kCandCap);   // hidden indices fit 16 bits (H <= 65536, use_fused); a larger
+                                                                     // one has flagged the row (any_nan) before it is read back
     static_assert(2 * kCandCap * 4 <= 64 * kRefTileStride * 4, "candidate keys must fit the W tile");
     bool any_nan = false;
     uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
@@ -1027,7 +1028,7 @@ __device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand,
             all_or |= kk;
             all_and &= kk;
             lkey[filled + i] = kk;
-            lidx[filled + i] = c.y;
+            lidx[filled + i] = static_cast<uint16_t>(c.y);
         }
         filled += np;
     }
@@ -1139,13 +1140,28 @@ __device__ __forceinline__ void refine_rank_decode(unsigned long long* ekey, int
         const int j1 = 64 + lane;
         const unsigned long long mine0 = lane < m ? ekey[lane] : 0ull, mine1 = j1 < m ? ekey[j1] : 0ull;
         int rank0 = 0, same0 = 0, rank1 = 0, same1 = 0;
+        // First on the value halves of the keys alone (32-bit compares): exact fp32 latents of one row are almost never equal, and
+        // if no lane sees its value twice the ranks are final and no unit can be listed twice.  Otherwise: the 64-bit walk.
+        const uint32_t* khi = reinterpret_cast<const uint32_t*>(ekey) + 1;          // high words, stride 2
+        const uint32_t v0 = static_cast<uint32_t>(mine0 >> 32), v1 = static_cast<uint32_t>(mine1 >> 32);
         if (m <= 64) {
             for (int i = 0; i < m; ++i) {
-                const unsigned long long other = ekey[i];
-                rank0 += (other > mine0) ? 1 : 0;
-                same0 += (other == mine0) ? 1 : 0;
+                const uint32_t other = khi[2 * i];
+                rank0 += (other > v0) ? 1 : 0;
+                same0 += (other == v0) ? 1 : 0;
             }
         } else {
+            for (int i = 0; i < m; ++i) {
+                const uint32_t other = khi[2 * i];
+                rank0 += (other > v0) ? 1 : 0;
+                same0 += (other == v0) ? 1 : 0;
+                rank1 += (other > v1) ? 1 : 0;
+                same1 += (other == v1) ? 1 : 0;
+            }
+        }
+        const bool tied = (lane < m && same0 != 1) || (j1 < m && same1 != 1);
+        if (__any(tied)) {
+            rank0 = same0 = rank1 = same1 = 0;
             for (int i = 0; i < m; ++i) {
                 const unsigned long long other = ekey[i];
                 rank0 += (other > mine0) ? 1 : 0;
@@ -1310,9 +1326,9 @@ constexpr int kSlMaxSlices = 64;
 constexpr int kSlRowsPerWave = 128;
 constexpr int kSlXRows = 40;           // distinct activation rows per batch of 64 pairs (more: the batch is cut short)
 constexpr int kSlQueue = 640;          // (row, entry) pairs per expansion round
-constexpr int kSlicedMinRows = 16384;  // below this a slice's share of the rows does not fill the chip
+constexpr int kSlicedMinRows = 8192;   // below this a slice's share of the rows does not fill the chip (tools/experiments/r03_sliced_batch_sizes.py)
 static_assert(kSlList * 8 <= kCandCap * 8, "sorted list + values must fit the row's candidate segment");
-constexpr int kSlSelectLds = 2 * kCandCap * 4 + kRefMaxSurv * 4;                                  // per wave
+constexpr int kSlSelectLds = kCandCap * 4 + kCandCap * 2 + kRefMaxSurv * 4;                          // per wave: keys | u16 indices | survivors
 constexpr int kSlChainLds = 64 * kRefTileStride * 4 + kSlXRows * kRefTileStride * 4 + kSlQueue * 4 + 64 * 4;
 constexpr int kSlRankLds = kRefMaxSurv * 8 + 2 * kRefMaxSurv * 4 + kRefMaxSurv * 4;
 
@@ -1326,7 +1342,7 @@ refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int 
     const int b = blockIdx.x * kRefWaves + wave;
     if (b >= B) return;
     float* wt = reinterpret_cast<float*>(sel_smem + static_cast<size_t>(wave) * kSlSelectLds);
-    int* hidx = reinterpret_cast<int*>(wt + 2 * kCandCap);
+    int* hidx = reinterpret_cast<int*>(sel_smem + static_cast<size_t>(wave) * kSlSelectLds + kCandCap * 6);
     auto flag_row = [&]() {
         if (lane == 0) {
             const int slot = atomicAdd(&flags[0], 1);
