@@ -807,6 +807,7 @@ constexpr int kRefWaves = 4;
 constexpr int kRefMaxD = 2048;
 constexpr int kRefSets = 3;        // W blocks in flight per wave
 constexpr int kRefMaxSurv = 256;   // survivors per row (more -> flagged, exact fallback)
+constexpr int kSelInFlight = 6;    // candidate-list slots per lane loaded together (refine_select_row)
 constexpr int kRefTileStride = 36; // floats per transposed-tile row (32 + 4 pad: conflict-free b128 access)
 // dynamic LDS per wave: exact keys [512] u64 | transposed W tile [64][36] | hidden index / value [512]
 __host__ __device__ static inline size_t ref_lds_per_wave(int) {
@@ -1020,15 +1021,26 @@ __device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand,
     for (int p = 0; p < parts; ++p) {
         const int np = p == 0 ? ((cint_t)cnt)[b] : ((cint_t)cnt_parts)[static_cast<size_t>(p - 1) * B + b];
         const uint2* seg = list + p * cap_part;
-        for (int i = lane; i < np; i += 64) {
-            const uint2 c = seg[i];
-            const float v = __uint_as_float(c.x);
-            const uint32_t kk = mono_key(v);
-            any_nan |= (v != v) || c.y >= static_cast<uint32_t>(H);     // (a hidden index outside the dictionary: never gather with it)
-            all_or |= kk;
-            all_and &= kk;
-            lkey[filled + i] = kk;
-            lidx[filled + i] = static_cast<uint16_t>(c.y);
+        for (int i0 = 0; i0 < np; i0 += 64 * kSelInFlight) {         // kSelInFlight list slots per lane in flight: one round trip
+            uint2 c[kSelInFlight];                                     // for the usual ~300 entries, not five
+#pragma unroll
+            for (int u = 0; u < kSelInFlight; ++u) {
+                const int i = i0 + 64 * u + lane;
+                c[u] = i < np ? seg[i] : uint2{0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < kSelInFlight; ++u) {
+                const int i = i0 + 64 * u + lane;
+                if (i < np) {
+                    const float v = __uint_as_float(c[u].x);
+                    const uint32_t kk = mono_key(v);
+                    any_nan |= (v != v) || c[u].y >= static_cast<uint32_t>(H);   // (a hidden index outside the dictionary: never gather with it)
+                    all_or |= kk;
+                    all_and &= kk;
+                    lkey[filled + i] = kk;
+                    lidx[filled + i] = static_cast<uint16_t>(c[u].y);
+                }
+            }
         }
         filled += np;
     }
