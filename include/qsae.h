@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QSAE_ABI_VERSION 3
+#define QSAE_ABI_VERSION 4
 
 #define QSAE_OK 0
 #define QSAE_ERR_INVALID_ARG (-1)  /* null pointer, non-positive dim, misaligned pointer      */
@@ -326,8 +326,8 @@ int qsae_encode_bits_band_submit(const float* x, const float* W, const float* bi
 int qsae_encode_bits_band_finish(const float* x, const float* W, const float* bias, const void* Wq, const float* meta,
                                  int B, int D, int H, uint32_t* zbits, int64_t words_ld, void* workspace,
                                  size_t workspace_bytes, int flagged, qsae_stream_t stream);
-/* Hidden-major dictionary for the sparse decoder: codes_rows[j][ceil(D/16)] uint32, 2-bit two's-complement
- * fields of S_j/2 (same S as qsae_pack_matryoshka). */
+/* Hidden-major dictionary for the sparse decoder: codes_rows[j][ceil(D/8)] uint32, 4-bit two's-complement
+ * fields of S_j/2 (same S as qsae_pack_matryoshka; ABI 4: 2-bit fields, ceil(D/16) words per row, until ABI 3). */
 int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,
                               qsae_stream_t stream);
 /* qsae_decode_matryoshka evaluated on the active units only (ascending walk over the row's z bits, one fmaf

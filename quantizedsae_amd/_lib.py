@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ["QSAE_HIP_LIB"]) if os.environ.get("QSAE_HIP_LIB") el
 # The debug build (same sources + -DQSAE_DEBUG_BUILD): process-wide qsae_debug_* switches and ablation kernels.  Never
 # loaded by the package itself; tools/ and a few tests ask for it explicitly (use_library("debug")).
 DEBUG_LIB_PATH = _PKG / "lib" / "libqsae_hip_debug.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_WORKSPACE = -1, -2, -3, -4

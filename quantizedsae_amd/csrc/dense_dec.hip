@@ -214,24 +214,42 @@ pack_matryoshka_rows_kernel(const float* __restrict__ w, const float* __restrict
     if (gid >= static_cast<long long>(H) * row_words) return;
     const int j = static_cast<int>(gid / row_words), wi = static_cast<int>(gid % row_words);
     uint32_t word = 0;
-    for (int f = 0; f < 16; ++f) {
-        const int d = wi * 16 + f;
+    for (int f = 0; f < 8; ++f) {
+        const int d = wi * 8 + f;
         if (d >= D) break;
         const long long o = static_cast<long long>(j) * D + d;
         const int half = (sig_ge_half(w[o]) ? 1 : -1) + (sig_ge_half(wm[o]) ? 1 : -1);   // -2, 0, 2
-        const uint32_t code = half == 0 ? 0u : (half > 0 ? 1u : 3u);
-        word |= code << (2 * f);
+        const uint32_t code = half == 0 ? 0u : (half > 0 ? 1u : 0xFu);                    // S / 2 as a 4-bit two's-complement field
+        word |= code << (4 * f);
     }
     codes_rows[gid] = word;
 }
 
+// low nibble of byte `byte` of w as a signed 4-bit integer / 16, in one instruction (decode_row.h has the same helper)
+__device__ __forceinline__ float sp_cvt_off_nibble(uint32_t w, int byte) {
+    float r;
+    if (byte == 0) asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(w));
+    else if (byte == 1) asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(w));
+    else if (byte == 2) asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(w));
+    else asm("v_cvt_off_f32_i4_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(w));
+    return r;
+}
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
+
+// Round 3: the walk is VALU-bound at ~200 active units per row (bit-field extract + convert + fma per unit and column, 24
+// instructions per 8 columns), so the dictionary rows are 4-bit fields now: v_cvt_off_f32_i4 converts a nibble in one
+// instruction (to S / 32: the factor goes to the scale, 32 scale_j is exact), two columns share a v_pk_fma_f32, and up to
+// eight units are in flight instead of four (a group ends at the level boundary, not before it).
 template <int FPL>   // output columns per lane: D = 64 * FPL
 __global__ void __launch_bounds__(64 * kSpWaves)
 decode_matryoshka_sparse_kernel(const uint32_t* __restrict__ zbits, int64_t words_ld, int B, int H,
                                 const uint32_t* __restrict__ codes_rows, const float* __restrict__ scale, LevelTable lv,
                                 const float* __restrict__ bias, float* __restrict__ levels, int64_t level_stride) {
     constexpr int D = 64 * FPL;
-    constexpr int ROW_WORDS = D / 16;
+    constexpr int ROW_WORDS = D / 8;
+    constexpr int NW = FPL >= 8 ? FPL / 8 : 1;             // dictionary words per lane and unit
+    constexpr int NP = FPL >= 2 ? FPL / 2 : 1;             // column pairs per lane
+    constexpr int kUnits = 8;                              // units in flight
     __shared__ uint16_t lists[kSpWaves][kSpRound];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,29 +257,39 @@ decode_matryoshka_sparse_kernel(const uint32_t* __restrict__ zbits, int64_t word
     if (b >= B) return;
     uint16_t* list = lists[wave];
     typedef const __attribute__((address_space(4))) float* cflt_t;
-    float acc[FPL];
+    sp_f32x2 acc[NP];
 #pragma unroll
-    for (int f = 0; f < FPL; ++f) acc[f] = 0.0f;
+    for (int p = 0; p < NP; ++p) acc[p] = sp_f32x2{0.0f, 0.0f};
     float bcol[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) bcol[f] = bias ? bias[lane * FPL + f] : 0.0f;
-    // this lane's FPL two-bit fields sit in word (lane*FPL)/16 of a dictionary row, from bit 2*((lane*FPL)%16) on
-    const int wsel = (lane * FPL) / 16;
-    const int wshift = 2 * ((lane * FPL) % 16);
+    // this lane's FPL four-bit fields: from word (lane*FPL)/8 of a dictionary row, bit 4*((lane*FPL)%8) on
+    const int wsel = (lane * FPL) / 8;
+    const int wshift = 4 * ((lane * FPL) % 8);
     int level = 0;
     auto write_level = [&](int lvl) {
         float* out = levels + static_cast<int64_t>(lvl) * level_stride + static_cast<int64_t>(b) * D + lane * FPL;
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) out[f] = acc[f] + bcol[f];
+        for (int f = 0; f < FPL; ++f) out[f] = acc[f >> 1][f & 1] + bcol[f];
     };
-    // the dense kernel's term is fmaf(scale_j, S, acc) with S in {-2, 0, 2}; 2 * scale_j is exact, so
-    // fmaf(2 * scale_j, S / 2, acc) rounds the same real number
-    auto add_unit = [&](int j, uint32_t cw, float a) {
-        const int w = static_cast<int>(cw >> wshift);
-        const float t = 2.0f * a;
+    // the dense kernel's term is fmaf(scale_j, S, acc) with S in {-2, 0, 2}; 32 scale_j is exact, so
+    // fmaf(32 scale_j, S / 32, acc) rounds the same real number (S / 32 = the field / 16)
+    auto add_unit = [&](const uint32_t (&cw)[NW], float a) {
+        const float t = 32.0f * a;
+        const sp_f32x2 t2 = {t, t};
 #pragma unroll
-        for (int f = 0; f < FPL; ++f)
-            acc[f] = fmaf(t, static_cast<float>(sbfe_i32(w, 2 * f, 2)), acc[f]);
+        for (int q = 0; q < NW; ++q) {
+            const uint32_t w = cw[q] >> (FPL >= 8 ? 0 : wshift);
+            const uint32_t odd = w >> 4;
+            if (FPL == 1) {
+                acc[0][0] = fmaf(t, sp_cvt_off_nibble(w, 0), acc[0][0]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < (FPL >= 8 ? 4 : FPL / 2); ++p)
+                    acc[4 * q + p] = __builtin_elementwise_fma(t2, sp_f32x2{sp_cvt_off_nibble(w, p), sp_cvt_off_nibble(odd, p)},
+                                                               acc[4 * q + p]);
+            }
+        }
     };
     const int words = H / 32;
     const uint32_t* zrow = zbits + static_cast<int64_t>(b) * words_ld;
@@ -287,26 +315,26 @@ decode_matryoshka_sparse_kernel(const uint32_t* __restrict__ zbits, int64_t word
         const int base = w0 * 32;
         int t = 0;
         while (t < total) {
-            // four units at a time while they stay inside the current level
-            if (t + 4 <= total && base + list[t + 3] < lv.end[level]) {
-                int j[4];
-                uint32_t cw[4];
-                float a[4];
+            // the next up to kUnits units (lane u holds unit t + u); the group ends where the level does
+            const int jl = (lane < kUnits && t + lane < total) ? base + list[t + lane] : 0x7FFFFFFF;
+            const int first = __builtin_amdgcn_readfirstlane(jl);
+            while (level < lv.n - 1 && first >= lv.end[level]) write_level(level++);
+            const bool inside = jl != 0x7FFFFFFF && (level == lv.n - 1 || jl < lv.end[level]);
+            const int n = __popcll(__ballot(inside));        // >= 1: the list is ascending, the units inside are a prefix
+            uint32_t cw[kUnits][NW];
+            float a[kUnits];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    j[u] = __builtin_amdgcn_readfirstlane(base + list[t + u]);
-                    cw[u] = codes_rows[static_cast<int64_t>(j[u]) * ROW_WORDS + wsel];
-                    a[u] = ((cflt_t)scale)[j[u]];
+            for (int u = 0; u < kUnits; ++u)
+                if (u < n) {
+                    const int j = __builtin_amdgcn_readlane(jl, u);
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) cw[u][q] = codes_rows[static_cast<int64_t>(j) * ROW_WORDS + wsel + q];
+                    a[u] = ((cflt_t)scale)[j];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) add_unit(j[u], cw[u], a[u]);
-                t += 4;
-            } else {
-                const int j = __builtin_amdgcn_readfirstlane(base + list[t]);
-                while (level < lv.n - 1 && j >= lv.end[level]) write_level(level++);
-                add_unit(j, codes_rows[static_cast<int64_t>(j) * ROW_WORDS + wsel], ((cflt_t)scale)[j]);
-                t += 1;
-            }
+            for (int u = 0; u < kUnits; ++u)
+                if (u < n) add_unit(cw[u], a[u]);
+            t += n;
         }
         asm volatile("" ::: "memory");
     }
@@ -467,7 +495,7 @@ extern "C" int qsae_decode_matryoshka(const uint32_t* zbits, int64_t words_ld, i
 extern "C" int qsae_pack_matryoshka_rows(const float* w, const float* wm, int H, int D, uint32_t* codes_rows,
                                          qsae_stream_t stream) {
     QSAE_CHECK_ARG(H > 0 && D > 0 && w && wm && codes_rows, "H > 0, D > 0, non-null pointers");
-    const int row_words = (D + 15) / 16;
+    const int row_words = (D + 7) / 8;
     const long long total = static_cast<long long>(H) * row_words;
     hipLaunchKernelGGL(pack_matryoshka_rows_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
                        as_stream(stream), w, wm, H, D, row_words, codes_rows);

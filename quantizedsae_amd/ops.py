@@ -803,10 +803,10 @@ def decode_matryoshka(zbits: torch.Tensor, H: int, D: int, n_bits: int, codes, s
 
 @_on_tensor_device
 def pack_matryoshka_rows(w: torch.Tensor, wm: torch.Tensor) -> torch.Tensor:
-    """-> codes_rows int32 [H, ceil(D/16)]: the dictionary in hidden-major order for decode_matryoshka_sparse."""
+    """-> codes_rows int32 [H, ceil(D/8)]: the dictionary in hidden-major order (4-bit fields) for decode_matryoshka_sparse."""
     w, wm = _f32c(w, "w"), _f32c(wm, "wm")
     H, D = w.shape
-    codes = torch.empty((H, (D + 15) // 16), dtype=torch.int32, device=w.device)
+    codes = torch.empty((H, (D + 7) // 8), dtype=torch.int32, device=w.device)
     check(_lib.load().qsae_pack_matryoshka_rows(_p(w), _p(wm), H, D, _p(codes), _stream()))
     return codes
 

@@ -314,7 +314,7 @@ def _pack_matryoshka_rows(w: Tensor, wm: Tensor) -> Tensor:
 
 @_pack_matryoshka_rows.register_fake
 def _(w, wm):
-    return _i32((w.shape[0], (w.shape[1] + 15) // 16), w)
+    return _i32((w.shape[0], (w.shape[1] + 7) // 8), w)
 
 
 @_op("decode_matryoshka")

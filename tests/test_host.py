@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert sorted(_lib.SIGNATURES) == declared          # the ctypes table binds exactly the header
-    assert _lib.load().qsae_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.load().qsae_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_product_library_has_no_debug_surface():
@@ -47,7 +47,7 @@ def test_product_library_has_no_debug_surface():
     dbg = {s_ for s_ in build.exported_symbols(_lib.DEBUG_LIB_PATH) if s_.startswith("qsae_")}
     assert declared <= dbg and any(s_.startswith("qsae_debug_") for s_ in dbg)
     with _lib.use_library("debug") as lib:
-        assert lib.qsae_abi_version() == 3 and _lib.load() is lib
+        assert lib.qsae_abi_version() == 4 and _lib.load() is lib
     assert _lib.load() is not lib
 
 

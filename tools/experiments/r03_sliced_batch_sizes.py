@@ -15,10 +15,23 @@ import bench  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.use_library("debug").__enter__()
 lib.qsae_debug_set_refine_sliced.argtypes = [C.c_int]
-model = bench.build_model(dev)
-model.latent_path = "prefilter"
-model.decoder.packed()
-for B in (2048, 4096, 8192, 16384, 32768, 65536, 131072):
+kind = sys.argv[1] if len(sys.argv) > 1 else "binary"          # binary (headline) | soft (unpolarised decoder: fp32 table) | baseline (top-32, fp32 table)
+if kind == "binary":
+    model = bench.build_model(dev)
+    model.latent_path = "prefilter"
+    model.decoder.packed()
+elif kind == "soft":
+    import warnings
+    from quantizedsae_amd import BinarySAE
+    warnings.simplefilter("ignore")
+    model = BinarySAE(bench.D, bench.H, gamma=bench.GAMMA, n_bits=bench.N_BITS).to(dev).eval()
+    with torch.no_grad():
+        model.decoder.weight.normal_(0, 2.0)
+else:
+    from quantizedsae_amd import BaselineSparseAutoencoder
+    model = BaselineSparseAutoencoder(bench.D, bench.H).to(dev).eval()
+print(kind)
+for B in ((2048, 4096, 8192, 16384, 32768, 65536, 131072) if kind == "binary" else (8192, 16384, 65536)):
     x = torch.randn((B, 512), device=dev)
     res = {}
     for form in (0, 2, 0, 2):
