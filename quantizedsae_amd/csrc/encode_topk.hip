@@ -1336,12 +1336,12 @@ refine_topk_kernel(const uint2* __restrict__ cand, const int* __restrict__ cnt, 
 constexpr int kSlList = 256;           // ints per row for the sorted survivor list; the exact values follow as kSlList floats
 constexpr int kSlMaxSlices = 64;
 constexpr int kSlRowsPerWave = 128;
-constexpr int kSlXRows = 40;           // distinct activation rows per batch of 64 pairs (more: the batch is cut short)
-constexpr int kSlQueue = 640;          // (row, entry) pairs per expansion round
+constexpr int kSlXRows = 24;           // distinct activation rows per batch of 64 pairs (more: the batch is cut short)
+constexpr int kSlQueue = 512;          // (row, entry) pairs per expansion round (16 bits each)
 constexpr int kSlicedMinRows = 8192;   // below this a slice's share of the rows does not fill the chip (tools/experiments/r03_sliced_batch_sizes.py)
 static_assert(kSlList * 8 <= kCandCap * 8, "sorted list + values must fit the row's candidate segment");
 constexpr int kSlSelectLds = kCandCap * 4 + kCandCap * 2 + kRefMaxSurv * 4;                          // per wave: keys | u16 indices | survivors
-constexpr int kSlChainLds = 64 * kRefTileStride * 4 + kSlXRows * kRefTileStride * 4 + kSlQueue * 4 + 64 * 4;
+constexpr int kSlChainLds = 64 * 32 * 4 + kSlXRows * kRefTileStride * 4 + kSlQueue * 2 + 32 * 4;      // W tile | x tile | queue | x row ids
 constexpr int kSlRankLds = kRefMaxSurv * 8 + 2 * kRefMaxSurv * 4 + kRefMaxSurv * 4;
 
 __global__ void __launch_bounds__(64 * kRefWaves)
@@ -1433,6 +1433,10 @@ refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int 
 }
 
 // one batch of <= 64 (row, entry) pairs: lane l runs the chain of pair l; NXL = line-loads per block for the activation rows
+// (8 rows each).  Registers and LDS are sized for THREE workgroups per CU (<= 168 VGPRs, 12.5 KiB per wave): the launch is
+// bound by how many gathers the CU keeps in flight, not by any one pipe.  W tile [64][32] floats without padding, 16-byte
+// chunk c of row r at chunk position c ^ (r & 7): the line-wise stores (8 lanes = one row) and the row-wise reads (8 lanes = 8
+// consecutive rows, one chunk index) both touch every bank once.  Two sets of 8 + NXL loads in flight, counted waits.
 template <int NXL>
 __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                                   uint2* __restrict__ cand, int cap, int D, int row0, uint32_t my, bool valid, int lane,
@@ -1455,8 +1459,15 @@ __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, c
     const char* xb = reinterpret_cast<const char*>(x);
     const int nblk = D / 32;
     constexpr int NL = 8 + NXL;                        // line-loads per block and lane
-    constexpr int kSets = NXL <= 2 ? 3 : 2;            // blocks in flight
+    constexpr int kSets = 2;                           // blocks in flight
+    constexpr int kChunks = 2;                         // 16-byte chunks of the two tile rows read per step of a block
     f32x4 st[kSets][NL];
+    // this lane's slots in the W tile: where its line-load chunks go, and where its own row's chunks are
+    float* wput = wt + (lane >> 3) * 32 + 4 * ((lane & 7) ^ ((lane >> 3) & 7));          // + 8 i rows (256 floats) per load
+    const float* wrow = wt + lane * 32;
+    const int wkey = lane & 7;
+    float* xput = xt + (lane >> 3) * kRefTileStride + 4 * (lane & 7);
+    const float* xrow_t = xt + rx * kRefTileStride;
     auto visible_load = [&](f32x4 (&sv)[NL], int blk) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) sv[i] = *reinterpret_cast<const f32x4*>(wb + woff[i] + 128 * blk);
@@ -1465,31 +1476,30 @@ __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, c
     };
     auto consume = [&](const f32x4 (&sv)[NL]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<f32x4*>(wt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[i];
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(wput + 256 * i) = sv[i];
 #pragma unroll
-        for (int i = 0; i < NXL; ++i)
-            *reinterpret_cast<f32x4*>(xt + (8 * i + (lane >> 3)) * kRefTileStride + 4 * (lane & 7)) = sv[8 + i];
-        asm volatile("" ::: "memory");
-        const float* mw = wt + lane * kRefTileStride;
-        const float* mx = xt + rx * kRefTileStride;
-        f32x4 w[8], xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            w[q] = *reinterpret_cast<const f32x4*>(mw + 4 * q);
-            xv[q] = *reinterpret_cast<const f32x4*>(mx + 4 * q);
-        }
+        for (int i = 0; i < NXL; ++i) *reinterpret_cast<f32x4*>(xput + 8 * kRefTileStride * i) = sv[8 + i];
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            acc = fmaf(xv[q][0], w[q][0], acc);
-            acc = fmaf(xv[q][1], w[q][1], acc);
-            acc = fmaf(xv[q][2], w[q][2], acc);
-            acc = fmaf(xv[q][3], w[q][3], acc);
+        for (int part = 0; part < 8 / kChunks; ++part) {  // (kChunks chunks at a time: 8 kChunks instead of 64 staging registers)
+            f32x4 w[kChunks], xv[kChunks];
+#pragma unroll
+            for (int q = 0; q < kChunks; ++q) {
+                w[q] = *reinterpret_cast<const f32x4*>(wrow + 4 * ((kChunks * part + q) ^ wkey));
+                xv[q] = *reinterpret_cast<const f32x4*>(xrow_t + 4 * (kChunks * part + q));
+            }
+#pragma unroll
+            for (int q = 0; q < kChunks; ++q) {
+                acc = fmaf(xv[q][0], w[q][0], acc);
+                acc = fmaf(xv[q][1], w[q][1], acc);
+                acc = fmaf(xv[q][2], w[q][2], acc);
+                acc = fmaf(xv[q][3], w[q][3], acc);
+            }
+            asm volatile("" : "+v"(acc) :: "memory");       // (the next step's reads stay behind this step's chain)
         }
     };
     // counted waits as in refine_chain_pass: asm loads (SGPR base, 32-bit lane offsets), loads retire in issue order, a set is
-    // always followed by kSets - 1 younger ones, so vmcnt(NL (kSets - 1)) means "this set has landed"
+    // always followed by one younger set, so vmcnt(NL) means "this set has landed"
     auto issue = [&](f32x4 (&sv)[NL], int blk) {
         const char* sw = wb + 128 * blk;                // wave-uniform
         const char* sx = xb + 128 * blk;
@@ -1498,21 +1508,19 @@ __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, c
 #pragma unroll
         for (int i = 0; i < NXL; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sv[8 + i]) : "v"(xoff[i]), "s"(sx));
     };
-    auto landed = [&](f32x4 (&sv)[NL]) {
 #define QSAE_SL_REGS8 "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7])
-        if (NXL == 1) asm volatile("s_waitcnt vmcnt(18)" : QSAE_SL_REGS8, "+v"(sv[8]));                                           // 2 x 9
-        else if (NXL == 2) asm volatile("s_waitcnt vmcnt(20)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[NL - 1]));                    // 2 x 10
-        else if (NXL == 4) asm volatile("s_waitcnt vmcnt(12)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[NL - 1]));
-        else asm volatile("s_waitcnt vmcnt(13)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[NL - 1]));
+    auto landed = [&](f32x4 (&sv)[NL]) {
+        if (NXL == 1) asm volatile("s_waitcnt vmcnt(9)" : QSAE_SL_REGS8, "+v"(sv[8]));
+        else if (NXL == 2) asm volatile("s_waitcnt vmcnt(10)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[NL - 1]));
+        else asm volatile("s_waitcnt vmcnt(11)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[NL - 1]));
     };
     auto all_landed = [&](f32x4 (&sv)[NL]) {
         if (NXL == 1) asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]));
         else if (NXL == 2) asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[NL - 1]));
-        else if (NXL == 4) asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[NL - 1]));
-        else asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[NL - 1]));
-#undef QSAE_SL_REGS8
+        else asm volatile("s_waitcnt vmcnt(0)" : QSAE_SL_REGS8, "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[NL - 1]));
     };
-    static_assert(NXL == 1 || NXL == 2 || NXL == 4 || NXL == 5, "wait counts above");
+#undef QSAE_SL_REGS8
+    static_assert(NXL == 1 || NXL == 2 || NXL == 3, "wait counts above");
     int t = 0;
     if (nblk >= kSets) {
         asm volatile("" : "+v"(acc));                   // the loads the compiler knows about (list entry, bias) retire first
@@ -1544,9 +1552,9 @@ __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, c
     }
     if (valid) reinterpret_cast<float*>(list)[kSlList + ent] = acc;
 }
-static_assert(kSlXRows == 40, "slice_chain_batch<5> fills exactly 40 tile rows");
+static_assert(kSlXRows == 24, "slice_chain_batch<3> fills exactly 24 tile rows");
 
-__global__ void __launch_bounds__(64 * kRefWaves, 2)
+__global__ void __launch_bounds__(64 * kRefWaves, 3)
 refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                           uint2* __restrict__ cand, int cap, const uint8_t* __restrict__ offs, int B, int D, int S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
@@ -1554,8 +1562,8 @@ refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* base = chain_smem + static_cast<size_t>(wave) * kSlChainLds;
     float* wt = reinterpret_cast<float*>(base);
-    float* xt = wt + 64 * kRefTileStride;
-    uint32_t* queue = reinterpret_cast<uint32_t*>(xt + kSlXRows * kRefTileStride);
+    float* xt = wt + 64 * 32;
+    uint16_t* queue = reinterpret_cast<uint16_t*>(xt + kSlXRows * kRefTileStride);
     int* xr = reinterpret_cast<int*>(queue + kSlQueue);
     // workgroup g runs on XCD g mod 8 (round-robin dispatch); XCD x owns slices x, x + 8, ... and takes them one after the other
     const int g = blockIdx.x, xcd = g & 7, q = g >> 3;
@@ -1590,7 +1598,7 @@ refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__
             int wrote = 0;
             for (int i = 0; i < c; ++i)
                 if (start + i < kSlQueue) {
-                    queue[start + i] = (static_cast<uint32_t>(64 * half + lane) << 8) | static_cast<uint32_t>(at[half] + i);
+                    queue[start + i] = static_cast<uint16_t>(((64 * half + lane) << 8) | (at[half] + i));   // row 7 bits | entry 8 bits
                     ++wrote;
                 }
             at[half] += wrote;
@@ -1619,8 +1627,7 @@ refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__
             asm volatile("" ::: "memory");
             if (R <= 8) slice_chain_batch<1>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
             else if (R <= 16) slice_chain_batch<2>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
-            else if (R <= 32) slice_chain_batch<4>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
-            else slice_chain_batch<5>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
+            else slice_chain_batch<3>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
             asm volatile("" ::: "memory");
             p0 += take;
         }

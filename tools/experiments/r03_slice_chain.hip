@@ -269,7 +269,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kLdsPerWave + extra_lds));
-    for (int S : {16, 24, 32}) {
+    for (int S : {16}) {
         std::vector<uint8_t> offs(static_cast<size_t>(S + 1) * B);
         const int per = H / S;
         for (int b = 0; b < B; ++b) {
