@@ -1338,6 +1338,7 @@ constexpr int kSlMaxSlices = 64;
 constexpr int kSlRowsPerWave = 128;
 constexpr int kSlXRows = 24;           // distinct activation rows per batch of 64 pairs (more: the batch is cut short)
 constexpr int kSlQueue = 512;          // (row, entry) pairs per expansion round (16 bits each)
+constexpr int kSlicedMinK = 48;       // below this the one-launch form is 2 % faster (k = 16, 32: one row-major pass per row); above, the sliced one (k = 65: 6 %, k = 128: 12 %)
 constexpr int kSlicedMinRows = 8192;   // below this a slice's share of the rows does not fill the chip (tools/experiments/r03_sliced_batch_sizes.py)
 static_assert(kSlList * 8 <= kCandCap * 8, "sorted list + values must fit the row's candidate segment");
 constexpr int kSlSelectLds = kCandCap * 4 + kCandCap * 2 + kRefMaxSurv * 4;                          // per wave: keys | u16 indices | survivors
@@ -1896,7 +1897,7 @@ static int prefilter_submit(const PrefCall& c) {
     // 5. survivors -> exact chain -> exact top-k (-> the row's reconstruction)
     const bool sliced = g_ref_sliced != 0 && g_ref_ablate == 0 && g_ref_stamps == nullptr && D % 32 == 0 && D / 32 >= 2 &&
                         static_cast<uint64_t>(H) * D * 4 < (1ull << 32) && static_cast<uint64_t>(B) * D * 4 < (1ull << 32) &&
-                        (g_ref_sliced == 2 || B >= kSlicedMinRows) && sliced_fits(H, D);
+                        (g_ref_sliced == 2 || (B >= kSlicedMinRows && k >= kSlicedMinK)) && sliced_fits(H, D);
     if ((g_x_phase & 2) && sliced) {
         // 5'. the same refinement as three launches, chains slice-major (see refine_select_kernel)
         int S = 0, per_shift = 0;

@@ -30,8 +30,14 @@ elif kind == "soft":
 else:
     from quantizedsae_amd import BaselineSparseAutoencoder
     model = BaselineSparseAutoencoder(bench.D, bench.H).to(dev).eval()
-print(kind)
-for B in ((2048, 4096, 8192, 16384, 32768, 65536, 131072) if kind == "binary" else (8192, 16384, 65536)):
+if len(sys.argv) > 2:                                              # another k (the classes derive theirs from the width / the constructor)
+    k = int(sys.argv[2])
+    if kind == "baseline":
+        model.k = k
+    else:
+        type(model).top_k = property(lambda self: k)
+print(kind, "k =", getattr(model, "top_k", getattr(model, "k", None)))
+for B in ((2048, 4096, 8192, 16384, 32768, 65536, 131072) if kind == "binary" and len(sys.argv) < 3 else (8192, 16384, 65536)):
     x = torch.randn((B, 512), device=dev)
     res = {}
     for form in (0, 2, 0, 2):

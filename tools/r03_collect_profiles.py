@@ -30,8 +30,8 @@ def means(run, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-TAGS = ("sweep_xstat_f16", "fill_zero_co", "refine_topk", "split_dec_bf16_kernel<0>", "split_dec_bf16_kernel<1>",
-        "gemm_nt_f32_kernel")
+TAGS = ("sweep_xstat_f16", "fill_zero_co", "refine_topk", "refine_select", "refine_slice_chain", "refine_rank",
+        "split_dec_bf16_kernel<0>", "split_dec_bf16_kernel<1>", "gemm_nt_f32_kernel")
 raw = {}
 for run in ("pmc_default", "pmc_split"):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
