@@ -148,7 +148,10 @@ decode_binary_sparse_kernel(const int32_t* __restrict__ idx, const float* __rest
     const long long off = b * k;
     sort_pairs_by_index(active, idx + off, val + off, k, H, lane, s_idx, s_val, tmp_idx[wave]);
     if (!active) return;
-    decode_row_sorted<FW>(s_idx, s_val, k, d, b, lane);
+    // 4- and 8-bit fields: all of a chunk's dictionary rows in flight (and the 13-instruction nibble form), as in the refinement
+    if (FW == 4) decode_row_sorted_wide4(s_idx, s_val, k, d, b, lane);
+    else if (FW == 8) decode_row_sorted_wide<8>(s_idx, s_val, k, d, b, lane);
+    else decode_row_sorted<FW>(s_idx, s_val, k, d, b, lane);
 }
 
 // rows != nullptr: row b of this launch is activation row rows[b] (as above)

@@ -118,7 +118,12 @@ __device__ __forceinline__ void decode_row_sorted_wide(const int* s_idx, const f
                                                        long long b, int lane) {
     constexpr int F = 32 / FW;
     static_assert(F <= 8, "the unrolled chunk is 64 F multiply-adds: fields of 4 bits or more only");
-    for (int c = lane; c < d.row_dwords; c += 64) {
+    // EVERY lane runs every round of this loop (lanes past the row's last dword re-read it and store nothing): the list
+    // entries travel between lanes through v_readlane, which reads a lane's register whether or not that lane is active --
+    // a lane that had left the loop would hand out whatever its register held
+    for (int c0 = 0; c0 < d.row_dwords; c0 += 64) {
+        const bool live = c0 + lane < d.row_dwords;
+        const int c = live ? c0 + lane : d.row_dwords - 1;
         float acc[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) acc[f] = 0.0f;
@@ -157,7 +162,7 @@ __device__ __forceinline__ void decode_row_sorted_wide(const int* s_idx, const f
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const int col = c * F + f;
-            if (col < d.D) {
+            if (live && col < d.D) {
                 float r = d.step * acc[f];          // rounded multiply, then rounded add (binary.py:38)
                 r = r + (d.bias ? d.bias[col] : 0.0f);
                 out[f] = r;
@@ -184,7 +189,9 @@ __device__ __forceinline__ float cvt_off_nibble(uint32_t w, int byte) {        /
 
 __device__ __forceinline__ void decode_row_sorted_wide_i4(const int* s_idx, const float* s_val, int k, const RowDecode& d,
                                                           long long b, int lane) {
-    for (int c = lane; c < d.row_dwords; c += 64) {
+    for (int c0 = 0; c0 < d.row_dwords; c0 += 64) {               // every lane runs every round (see decode_row_sorted_wide)
+        const bool live = c0 + lane < d.row_dwords;
+        const int c = live ? c0 + lane : d.row_dwords - 1;
         dec_f32x2 acc[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) acc[p] = dec_f32x2{0.0f, 0.0f};
@@ -221,7 +228,7 @@ __device__ __forceinline__ void decode_row_sorted_wide_i4(const int* s_idx, cons
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             const int col = c * 8 + f;
-            if (col < d.D) {
+            if (live && col < d.D) {
                 float r = d.step * acc[f >> 1][f & 1];          // rounded multiply, then rounded add (binary.py:38)
                 r = r + (d.bias ? d.bias[col] : 0.0f);
                 out[f] = r;
