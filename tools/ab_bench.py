@@ -6,6 +6,12 @@
                                                             # on the GPU box: one child process per (round, tag), interleaved
   (TAG "base" = the product library of the tree, no extra defines)
 
+Switches the sources know (each keeps the earlier form of one round-3 change, for the numbers quoted in DESIGN.md 8):
+  -DQSAE_AB_NO_SLICED=1      refinement as one launch at every batch size (no select / slice-major chains / rank)
+  -DQSAE_AB_NARROW_DECODE=1  row decode with four dictionary rows in flight
+  -DQSAE_AB_NO_DUAL=1        no second chains on the low lanes of the one-launch refinement
+  -DQSAE_AB_FULL_BISECT=1    bisection of the approximate k-th value down to the last key bit
+
 Variant libraries live under build/ab/ (git-ignored, they travel with the gpurun snapshot).  The child process points the ctypes
 loader at the variant before the package's first call; nothing in the package knows about variants."""
 import argparse
