@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the round-3 paths on fresh random batches (different data scales and biases every iteration):
-  * BinarySAE soft (table decode inside the refinement) and BaselineSparseAutoencoder through forward_submit, two in flight,
-    against the exact-fp32 fused path + separate decode (bit for bit);
+  * BinarySAE soft (table decode inside the refinement), BinarySAE polarised (the headline: sliced refinement, 13-instruction
+    nibble decode) and BaselineSparseAutoencoder through forward_submit, two in flight, against the exact-fp32 fused path +
+    separate decode (bit for bit);
   * qsae_encode_bits_band against qsae_encode_bits (bit for bit) at a random activation density;
   * split ternary / matryoshka decoders against the fp32 kernels (1e-5 relative).
 usage: python tools/stress_round3.py [iterations]"""
@@ -21,8 +22,11 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B, D, H = 65536, 512, 32768
 g = torch.Generator(device=dev); g.manual_seed(11)
 soft = BinarySAE(D, H, gamma=4.0, n_bits=4).to(dev).eval()
+hard = BinarySAE(D, H, gamma=4.0, n_bits=4).to(dev).eval()
 base = BaselineSparseAutoencoder(D, H).to(dev).eval()
 with torch.no_grad():
+    hard.decoder.weight.copy_(torch.where(torch.rand(hard.decoder.weight.shape, device=dev, generator=g) > 0.5, 30.0, -30.0))
+    hard.encoder[0].bias.copy_(torch.randn((H,), device=dev, generator=g) * 0.05)
     soft.decoder.weight.copy_(torch.randn(soft.decoder.weight.shape, device=dev, generator=g) * 2.0)
     soft.encoder[0].bias.copy_(torch.randn((H,), device=dev, generator=g) * 0.05)
 w = torch.randn((D, H), device=dev, generator=g) * 0.5
@@ -35,7 +39,7 @@ for it in range(N):
     scale = float(10.0 ** (torch.rand((), generator=g, device=dev) * 4 - 2))
     x = torch.randn((B, D), device=dev, generator=g) * scale
     x[torch.randint(0, B, (3,), device=dev, generator=g)] = float("nan") if it % 5 == 0 else 0.0
-    for name, model in (("soft", soft), ("base", base)):
+    for name, model in (("soft", soft), ("hard", hard), ("base", base)):
         h = model.forward_submit(x, slot=it % 2)
         if name in pend:
             px, ph = pend[name]
