@@ -1906,13 +1906,16 @@ static int prefilter_submit(const PrefCall& c) {
         QSAE_SET_MAX_LDS_ONCE(refine_select_kernel, 160 * 1024);
         QSAE_SET_MAX_LDS_ONCE(refine_slice_chain_kernel, 160 * 1024);
         const dim3 rows_grid((B + kRefWaves - 1) / kRefWaves), block(64 * kRefWaves);
-        hipLaunchKernelGGL(refine_select_kernel, rows_grid, block, kSlSelectLds * kRefWaves, s, cand, cnt, kCandCap, tau, margin, B, H, k,
-                           parts, cnt_parts, flags, S, per_shift, offs);
-        QSAE_LAUNCH_CHECK();
-        const int wgs_per_slice = (B + kSlRowsPerWave * kRefWaves - 1) / (kSlRowsPerWave * kRefWaves);
-        hipLaunchKernelGGL(refine_slice_chain_kernel, dim3(8 * (S / 8) * wgs_per_slice), block, kSlChainLds * kRefWaves, s, c.x, c.W,
-                           c.bias, cand, kCandCap, offs, B, D, S);
-        QSAE_LAUNCH_CHECK();
+        if (!(g_x_phase & 8)) {                             // (debug library, timing experiments: 8 = the rank launch only, 4 = all but it)
+            hipLaunchKernelGGL(refine_select_kernel, rows_grid, block, kSlSelectLds * kRefWaves, s, cand, cnt, kCandCap, tau, margin, B,
+                               H, k, parts, cnt_parts, flags, S, per_shift, offs);
+            QSAE_LAUNCH_CHECK();
+            const int wgs_per_slice = (B + kSlRowsPerWave * kRefWaves - 1) / (kSlRowsPerWave * kRefWaves);
+            hipLaunchKernelGGL(refine_slice_chain_kernel, dim3(8 * (S / 8) * wgs_per_slice), block, kSlChainLds * kRefWaves, s, c.x,
+                               c.W, c.bias, cand, kCandCap, offs, B, D, S);
+            QSAE_LAUNCH_CHECK();
+        }
+        if (g_x_phase & 4) return QSAE_OK;
         const RowDecode rd = c.dec ? *c.dec : RowDecode{nullptr, 0, 0, 0, 0, 0.f, nullptr, nullptr, nullptr};
         auto rank = refine_rank_kernel<0>;
         if (!rd.active()) rank = refine_rank_kernel<3>;
