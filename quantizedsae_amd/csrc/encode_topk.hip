@@ -1441,11 +1441,10 @@ refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int 
 template <int NXL>
 __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                                                   uint2* __restrict__ cand, int cap, int D, int row0, uint32_t my, bool valid, int lane,
-                                                  float* wt, float* xt, const int* xr, int R, int rx) {
+                                                  float* wt, float* xt, const int* xr, int R, int rx, int h) {
     const int b = row0 + static_cast<int>(my >> 8), ent = static_cast<int>(my & 255u);
     int* list = reinterpret_cast<int*>(cand + static_cast<int64_t>(b) * cap);
-    const int h = list[ent];
-    float acc = bias ? bias[h] : 0.0f;
+    float acc = bias ? bias[h] : 0.0f;                  // (in flight beside the first two sets below)
     uint32_t woff[8], xoff[NXL];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1524,9 +1523,11 @@ __device__ __forceinline__ void slice_chain_batch(const float* __restrict__ x, c
     static_assert(NXL == 1 || NXL == 2 || NXL == 3, "wait counts above");
     int t = 0;
     if (nblk >= kSets) {
-        asm volatile("" : "+v"(acc));                   // the loads the compiler knows about (list entry, bias) retire first
 #pragma unroll
         for (int q = 0; q < kSets; ++q) issue(st[q], q);
+        // the loads the compiler knows about (the bias, the caller's prefetch for the next batch) retire here, once, as vmcnt(0)
+        // together with the two sets just issued -- not at the first use of acc inside the loop, in every round
+        asm volatile("" : "+v"(acc));
         for (; t + 2 * kSets <= nblk; t += kSets) {
 #pragma unroll
             for (int q = 0; q < kSets; ++q) {
@@ -1609,11 +1610,19 @@ refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__
         total = total < kSlQueue ? total : kSlQueue;
         asm volatile("" ::: "memory");
         // ---- batches of up to 64 pairs, cut short where the activation tile would overflow ----
+        // the hidden index and the bias of a pair are two dependent loads in front of its chain: the indices of the NEXT batch are
+        // loaded while this batch's chains run (the queue says which pairs come next), the bias beside the chain's first gathers
+        auto pair_h = [&](uint32_t q) {
+            const int* l = reinterpret_cast<const int*>(cand + static_cast<int64_t>(row0 + static_cast<int>(q >> 8)) * cap);
+            return l[q & 255u];
+        };
         int p0 = 0;
+        int h_next = pair_h(queue[lane < total ? lane : 0]);
         while (p0 < total) {
             const int p = p0 + lane;
             const bool in = p < total;
             const uint32_t my = queue[in ? p : p0];
+            const int h_now = h_next;
             const int rl = static_cast<int>(my >> 8);
             const int prev = __shfl_up(rl, 1, 64);
             const bool head = in && (lane == 0 || prev != rl);
@@ -1626,9 +1635,14 @@ refine_slice_chain_kernel(const float* __restrict__ x, const float* __restrict__
             if (head && valid) xr[rx] = row0 + rl;
             rx = valid ? rx : 0;
             asm volatile("" ::: "memory");
-            if (R <= 8) slice_chain_batch<1>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
-            else if (R <= 16) slice_chain_batch<2>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
-            else slice_chain_batch<3>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx);
+            {
+                const int pn = p0 + take + lane;                        // the next batch starts at p0 + take
+                const uint32_t qn = queue[pn < total ? pn : (p0 + take < total ? p0 + take : 0)];
+                h_next = pair_h(qn);
+            }
+            if (R <= 8) slice_chain_batch<1>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx, h_now);
+            else if (R <= 16) slice_chain_batch<2>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx, h_now);
+            else slice_chain_batch<3>(x, W, bias, cand, cap, D, row0, my, valid, lane, wt, xt, xr, R, rx, h_now);
             asm volatile("" ::: "memory");
             p0 += take;
         }

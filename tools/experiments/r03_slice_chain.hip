@@ -45,7 +45,11 @@ __device__ __forceinline__ void run_batch(const float* __restrict__ x, const flo
     for (int i = 0; i < NXL; ++i) {
         int tr = 8 * i + (lane >> 3);
         tr = tr < R ? tr : R - 1;
+#if ABL == 5   // every batch reads its activation rows from the same 64 rows (what an x-resident form would save)
+        xoff[i] = static_cast<uint32_t>(xr[tr] & 63) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
+#else
         xoff[i] = static_cast<uint32_t>(xr[tr]) * static_cast<uint32_t>(D * 4) + 16u * (lane & 7);
+#endif
     }
     const char* wb = reinterpret_cast<const char*>(W);
     const char* xb = reinterpret_cast<const char*>(x);
