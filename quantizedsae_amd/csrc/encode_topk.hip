@@ -985,7 +985,9 @@ __device__ __forceinline__ void refine_chain_pass(int j0, int m, int nx, int lan
 // Front half of the refinement of one row (one wave): the row's candidate list -> LDS, the approximate k-th largest value, the
 // cut, the survivors' hidden indices into hidx[0 .. m) (list order).  Returns m, or -1 if the row was handed to the exact kernels
 // (flag_row called).  `wt` is the wave's W-tile space (>= 2 kCandCap words), used for the staged list.
-template <class FlagFn, class StampFn>
+// kIdxInLds = false (single-part lists only): the hidden indices are not staged; the ~70 survivors fetch theirs from the list
+// again (L2 hits) and the wave needs 5 KiB of LDS instead of 7 -- the select launch is a latency chain, waves per CU are its rate.
+template <bool kIdxInLds = true, class FlagFn, class StampFn>
 __device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand, const int* __restrict__ cnt, int cap,
                                                  const float* __restrict__ tau, const float* __restrict__ margin, int B, int H, int k,
                                                  int parts, const int* __restrict__ cnt_parts, int b, int lane, float* wt, int* hidx,
@@ -1038,7 +1040,7 @@ __device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand,
                     all_or |= kk;
                     all_and &= kk;
                     lkey[filled + i] = kk;
-                    lidx[filled + i] = static_cast<uint16_t>(c[u].y);
+                    if (kIdxInLds) lidx[filled + i] = static_cast<uint16_t>(c[u].y);
                 }
             }
         }
@@ -1101,7 +1103,7 @@ __device__ __forceinline__ int refine_select_row(const uint2* __restrict__ cand,
         const unsigned long long msk = __ballot(keep);
         if (keep) {
             const int pos = m + __popcll(msk & ((1ull << lane) - 1ull));
-            if (pos < kRefMaxSurv) hidx[pos] = static_cast<int>(lidx[i]);
+            if (pos < kRefMaxSurv) hidx[pos] = kIdxInLds ? static_cast<int>(lidx[i]) : static_cast<int>(list[i].y);
         }
         m += __popcll(msk);
     }
@@ -1342,9 +1344,11 @@ constexpr int kSlicedMinK = 48;       // below this the one-launch form is 2 % f
 constexpr int kSlicedMinRows = 8192;   // below this a slice's share of the rows does not fill the chip (tools/experiments/r03_sliced_batch_sizes.py)
 static_assert(kSlList * 8 <= kCandCap * 8, "sorted list + values must fit the row's candidate segment");
 constexpr int kSlSelectLds = kCandCap * 4 + kCandCap * 2 + kRefMaxSurv * 4;                          // per wave: keys | u16 indices | survivors
+constexpr int kSlSelectLdsNoIdx = kCandCap * 4 + kRefMaxSurv * 4;                                  // per wave: keys | survivors
 constexpr int kSlChainLds = 64 * 32 * 4 + kSlXRows * kRefTileStride * 4 + kSlQueue * 2 + 32 * 4;      // W tile | x tile | queue | x row ids
 constexpr int kSlRankLds = kRefMaxSurv * 8 + 2 * kRefMaxSurv * 4 + kRefMaxSurv * 4;
 
+template <bool kIdxInLds>     // false: single-part lists (large batches), 5 KiB of LDS per wave -> 32 waves per CU
 __global__ void __launch_bounds__(64 * kRefWaves)
 refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int cap, const float* __restrict__ tau,
                      const float* __restrict__ margin, int B, int H, int k, int parts, const int* __restrict__ cnt_parts,
@@ -1354,8 +1358,9 @@ refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x * kRefWaves + wave;
     if (b >= B) return;
-    float* wt = reinterpret_cast<float*>(sel_smem + static_cast<size_t>(wave) * kSlSelectLds);
-    int* hidx = reinterpret_cast<int*>(sel_smem + static_cast<size_t>(wave) * kSlSelectLds + kCandCap * 6);
+    constexpr int kLds = kIdxInLds ? kSlSelectLds : kSlSelectLdsNoIdx;
+    float* wt = reinterpret_cast<float*>(sel_smem + static_cast<size_t>(wave) * kLds);
+    int* hidx = reinterpret_cast<int*>(sel_smem + static_cast<size_t>(wave) * kLds + (kIdxInLds ? kCandCap * 6 : kCandCap * 4));
     auto flag_row = [&]() {
         if (lane == 0) {
             const int slot = atomicAdd(&flags[0], 1);
@@ -1367,8 +1372,8 @@ refine_select_kernel(uint2* __restrict__ cand, const int* __restrict__ cnt, int 
         for (int s = lane; s <= S; s += 64) offs[static_cast<size_t>(s) * B + b] = 0;
     };
     float tau_b, margin_b;
-    int m = refine_select_row(cand, cnt, cap, tau, margin, B, H, k, parts, cnt_parts, b, lane, wt, hidx, flag_row, no_stamp, tau_b,
-                              margin_b);
+    int m = refine_select_row<kIdxInLds>(cand, cnt, cap, tau, margin, B, H, k, parts, cnt_parts, b, lane, wt, hidx, flag_row, no_stamp,
+                                         tau_b, margin_b);
     if (m > 255) { flag_row(); m = -1; }                               // (offsets are bytes)
     if (m < 0) { no_survivors(); return; }
     asm volatile("" ::: "memory");
@@ -1917,12 +1922,16 @@ static int prefilter_submit(const PrefCall& c) {
         int S = 0, per_shift = 0;
         sliced_plan(H, D, &S, &per_shift);
         uint8_t* offs = reinterpret_cast<uint8_t*>(ws + PL.sl_offs);
-        QSAE_SET_MAX_LDS_ONCE(refine_select_kernel, 160 * 1024);
+        QSAE_SET_MAX_LDS_ONCE(refine_select_kernel<true>, 160 * 1024);
         QSAE_SET_MAX_LDS_ONCE(refine_slice_chain_kernel, 160 * 1024);
         const dim3 rows_grid((B + kRefWaves - 1) / kRefWaves), block(64 * kRefWaves);
         if (!(g_x_phase & 8)) {                             // (debug library, timing experiments: 8 = the rank launch only, 4 = all but it)
-            hipLaunchKernelGGL(refine_select_kernel, rows_grid, block, kSlSelectLds * kRefWaves, s, cand, cnt, kCandCap, tau, margin, B,
-                               H, k, parts, cnt_parts, flags, S, per_shift, offs);
+            if (parts == 1)
+                hipLaunchKernelGGL(refine_select_kernel<false>, rows_grid, block, kSlSelectLdsNoIdx * kRefWaves, s, cand, cnt, kCandCap,
+                                   tau, margin, B, H, k, parts, cnt_parts, flags, S, per_shift, offs);
+            else
+                hipLaunchKernelGGL(refine_select_kernel<true>, rows_grid, block, kSlSelectLds * kRefWaves, s, cand, cnt, kCandCap, tau,
+                                   margin, B, H, k, parts, cnt_parts, flags, S, per_shift, offs);
             QSAE_LAUNCH_CHECK();
             const int wgs_per_slice = (B + kSlRowsPerWave * kRefWaves - 1) / (kSlRowsPerWave * kRefWaves);
             hipLaunchKernelGGL(refine_slice_chain_kernel, dim3(8 * (S / 8) * wgs_per_slice), block, kSlChainLds * kRefWaves, s, c.x,
