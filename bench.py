@@ -465,8 +465,11 @@ def main():
                        "latent_path": path_used, "batches_in_flight": args.pipeline,
                        "precision_note": ("every returned value (latent, reconstruction, MSE) is exact fp32 and bit-identical "
                                           "to the fp32-only path; with latent_path='prefilter' an fp16 MFMA pass with a rigorous "
-                                          "per-row error bound only selects ~80 candidate hidden units per row, which are then "
-                                          "re-evaluated with the exact fp32 fmaf chain and ranked exactly (DESIGN.md 4.2b)")},
+                                          "per-row error bound only selects ~70 candidate hidden units per row, which are then "
+                                          "re-evaluated with the exact fp32 fmaf chain and ranked exactly (DESIGN.md 7); at this "
+                                          "batch size the re-evaluation runs slice-major over the hidden units (select / chains "
+                                          "with a 4-MiB slice of the encoder weights resident in each XCD's L2 / rank + row "
+                                          "decode, DESIGN.md 7.6)")},
             "recon_mse": mse,
             "forward_blocking": {"value": world * B * args.steps / el_block, "unit": "activations/s",
                                  "ms_per_step": el_block / args.steps * 1e3, "steps": args.steps, "recon_mse": mse_block,
