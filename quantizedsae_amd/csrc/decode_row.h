@@ -200,21 +200,23 @@ __device__ __forceinline__ void decode_row_sorted_wide_i4(const int* s_idx, cons
             const int myi = s_idx[jl < k ? jl : j0];
             const float mya = jl < k ? 16.0f * s_val[jl] : 0.0f;
             const int rem = k - j0;                                      // wave-uniform; entries of this chunk: min(rem, 64)
-            // eight groups of eight entries, each behind a wave-uniform guard (k = 65 leaves one entry for the second chunk:
-            // one group, not 32 padded entries); all loads of the chunk are issued before the first is consumed
+            // eight groups of eight entries, each group and each entry behind a wave-uniform guard (k = 65 leaves one entry for the
+            // second chunk: one load and 13 instructions, not 32 padded entries); all loads of the chunk are issued before the first
+            // is consumed
             uint32_t w[64];
 #pragma unroll
             for (int g = 0; g < 8; ++g)
                 if (rem > 8 * g) {
 #pragma unroll
                     for (int u = 8 * g; u < 8 * g + 8; ++u)
-                        w[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, u)) * d.row_dwords + c];
+                        if (rem > u) w[u] = d.packed[static_cast<long long>(__builtin_amdgcn_readlane(myi, u)) * d.row_dwords + c];
                 }
 #pragma unroll
             for (int g = 0; g < 8; ++g)
                 if (rem > 8 * g) {
 #pragma unroll
                     for (int u = 8 * g; u < 8 * g + 8; ++u) {
+                        if (rem <= u) continue;                           // (wave-uniform: no padded entry is loaded or multiplied)
                         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mya), u));
                         const dec_f32x2 a2 = {a, a};
                         const uint32_t odd = w[u] >> 4;

@@ -1158,11 +1158,20 @@ __device__ __forceinline__ void refine_rank_decode(unsigned long long* ekey, int
         // if no lane sees its value twice the ranks are final and no unit can be listed twice.  Otherwise: the 64-bit walk.
         const uint32_t* khi = reinterpret_cast<const uint32_t*>(ekey) + 1;          // high words, stride 2
         const uint32_t v0 = static_cast<uint32_t>(mine0 >> 32), v1 = static_cast<uint32_t>(mine1 >> 32);
-        if (m <= 64) {
+        if (m <= 64 + 8) {
+            // one walk for the first 64 keys; a short tail (k = 64: ~5 keys beyond the 64th) is ranked by the whole wave, two
+            // ballots per tail key and slot, instead of a second compare / add pair in every round of the walk
             for (int i = 0; i < m; ++i) {
                 const uint32_t other = khi[2 * i];
                 rank0 += (other > v0) ? 1 : 0;
                 same0 += (other == v0) ? 1 : 0;
+            }
+            for (int e = 64; e < m; ++e) {
+                const uint32_t ve = khi[2 * e];                          // broadcast read
+                const bool in0 = lane < m, in1 = j1 < m;
+                const int r = __popcll(__ballot(in0 && v0 > ve)) + __popcll(__ballot(in1 && v1 > ve));
+                const int q = __popcll(__ballot(in0 && v0 == ve)) + __popcll(__ballot(in1 && v1 == ve));
+                if (j1 == e) { rank1 = r; same1 = q; }
             }
         } else {
             for (int i = 0; i < m; ++i) {
@@ -1219,9 +1228,30 @@ __device__ __forceinline__ void refine_rank_decode(unsigned long long* ekey, int
         for (int t = 0; t < (kRefMaxSurv + 63) / 64; ++t) {
             const int j = 64 * t + lane;
             pos[t] = -1;
+            mine_i[t] = 0x7FFFFFFF;                                      // (no entry: above every hidden index)
+            mine_v[t] = 0.0f;
             if (64 * t < k && j < k) {
                 mine_i[t] = w_idx[j];
                 mine_v[t] = w_val[j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < (kRefMaxSurv + 63) / 64; ++t) {
+            const int j = 64 * t + lane;
+            const int tail = k - 64 * t;                                 // entries of this slot (wave-uniform)
+            if (tail <= 0) continue;
+            if (tail <= 8 && t > 0) {
+                // a short last slot (k = 65: one entry): the wave counts for each of its entries together -- one ballot per slot
+                // of held indices -- instead of walking all k entries with one lane active
+                for (int e = 0; e < tail; ++e) {
+                    const int he = w_idx[64 * t + e];                    // broadcast read
+                    int c = 0;
+#pragma unroll
+                    for (int tt = 0; tt < (kRefMaxSurv + 63) / 64; ++tt)
+                        if (64 * tt < k) c += __popcll(__ballot(mine_i[tt] < he));
+                    if (lane == e) pos[t] = c;
+                }
+            } else if (j < k) {
                 int p = 0;
                 for (int i = 0; i < k; ++i) p += (w_idx[i] < mine_i[t]) ? 1 : 0;   // hidden indices are distinct
                 pos[t] = p;
