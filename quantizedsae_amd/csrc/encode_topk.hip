@@ -1158,31 +1158,29 @@ __device__ __forceinline__ void refine_rank_decode(unsigned long long* ekey, int
         // if no lane sees its value twice the ranks are final and no unit can be listed twice.  Otherwise: the 64-bit walk.
         const uint32_t* khi = reinterpret_cast<const uint32_t*>(ekey) + 1;          // high words, stride 2
         const uint32_t v0 = static_cast<uint32_t>(mine0 >> 32), v1 = static_cast<uint32_t>(mine1 >> 32);
+        // (no equality counts in these walks: with rank = number of larger values, any tie lowers the sum of the ranks below
+        // m (m - 1) / 2 -- a group of g equal values gets one rank instead of g consecutive ones -- so one wave reduction
+        // afterwards tells whether the 64-bit walk is needed)
         if (m <= 64 + 8) {
-            // one walk for the first 64 keys; a short tail (k = 64: ~5 keys beyond the 64th) is ranked by the whole wave, two
-            // ballots per tail key and slot, instead of a second compare / add pair in every round of the walk
-            for (int i = 0; i < m; ++i) {
-                const uint32_t other = khi[2 * i];
-                rank0 += (other > v0) ? 1 : 0;
-                same0 += (other == v0) ? 1 : 0;
-            }
+            // one walk for the first 64 keys; a short tail (k = 64: ~5 keys beyond the 64th) is ranked by the whole wave, one
+            // ballot per tail key and slot, instead of a second compare / add pair in every round of the walk
+            for (int i = 0; i < m; ++i) rank0 += (khi[2 * i] > v0) ? 1 : 0;
             for (int e = 64; e < m; ++e) {
                 const uint32_t ve = khi[2 * e];                          // broadcast read
-                const bool in0 = lane < m, in1 = j1 < m;
-                const int r = __popcll(__ballot(in0 && v0 > ve)) + __popcll(__ballot(in1 && v1 > ve));
-                const int q = __popcll(__ballot(in0 && v0 == ve)) + __popcll(__ballot(in1 && v1 == ve));
-                if (j1 == e) { rank1 = r; same1 = q; }
+                const int r = __popcll(__ballot(lane < m && v0 > ve)) + __popcll(__ballot(j1 < m && v1 > ve));
+                if (j1 == e) rank1 = r;
             }
         } else {
             for (int i = 0; i < m; ++i) {
                 const uint32_t other = khi[2 * i];
                 rank0 += (other > v0) ? 1 : 0;
-                same0 += (other == v0) ? 1 : 0;
                 rank1 += (other > v1) ? 1 : 0;
-                same1 += (other == v1) ? 1 : 0;
             }
         }
-        const bool tied = (lane < m && same0 != 1) || (j1 < m && same1 != 1);
+        int rsum = (lane < m ? rank0 : 0) + (j1 < m ? rank1 : 0);
+        for (int off = 32; off > 0; off >>= 1) rsum += __shfl_xor(rsum, off, 64);
+        same0 = same1 = 1;
+        const bool tied = rsum != m * (m - 1) / 2;
         if (__any(tied)) {
             rank0 = same0 = rank1 = same1 = 0;
             for (int i = 0; i < m; ++i) {

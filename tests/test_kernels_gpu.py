@@ -897,3 +897,29 @@ def test_sliced_refinement_sorts_lists_that_are_not_in_slice_order(sliced_refine
     assert 11 <= info["flagged_rows"] < 40
     assert np.array_equal(host(idx), want_idx)
     assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32))
+
+
+def test_sliced_refinement_ranks_equal_latents_like_the_oracle(sliced_refinement):
+    """Hidden units with identical weights give identical exact latents in every row: the rank launch first ranks on the
+    32-bit value keys, notices the tie (the ranks no longer sum to m (m - 1) / 2) and redoes the walk on the 64-bit keys, whose
+    low half is the oracle's tie-break (lower index first).  Pairs and a triple, scaled so that they sit in most rows' top-k."""
+    ops = _ops()
+    lib = sliced_refinement
+    B, D, H, k = 700, 512, 8192, 65
+    x = S.activations(198, B, D)
+    W = S.xavier_uniform(198, H, D, stream=1)
+    bias = S.normal(198, (H,), stream=3, std=0.05)
+    for src, dsts in ((3, (10,)), (4000, (500,)), (77, (78, 8000))):
+        W[src] *= 3.0
+        for d in dsts:
+            W[d] = W[src]
+            bias[d] = bias[src]
+    want_idx, want_val = oracle.topk(oracle.encode(x, W, bias), k)
+    tied_rows = sum(len(np.unique(want_val[b])) < k for b in range(B))
+    assert tied_rows > B // 4                              # the case is exercised
+    for form in (2, 0):
+        lib.qsae_debug_set_refine_sliced(form)
+        idx, val, dense = _prefilter(ops, x, W, bias, k)
+        assert np.array_equal(host(idx), want_idx), form
+        assert np.array_equal(host(val).view(np.uint32), want_val.view(np.uint32)), form
+    lib.qsae_debug_set_refine_sliced(2)
