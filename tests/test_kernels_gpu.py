@@ -785,10 +785,12 @@ def sliced_refinement(fused_path):
 
 
 @pytest.mark.parametrize("B,D,H,k", [(1000, 512, 8192, 65), (300, 64, 4096, 8), (2100, 512, 32768, 65), (515, 256, 16384, 32),
-                                     (700, 1024, 8192, 64), (129, 64, 4100, 3), (640, 512, 8192, 130)])
+                                     (700, 1024, 8192, 64), (129, 64, 4100, 3), (640, 512, 8192, 130), (1030, 512, 32768, 20)])
 def test_sliced_refinement_equals_oracle_and_the_one_launch_form(sliced_refinement, B, D, H, k):
     """select / slice-major chains / rank == the oracle's top-k, and bit for bit the one-launch refinement; rows not a
-    multiple of the 128-row wave tasks, one to many slices (H D 4 / 4 MiB rounded to eight), k on both sides of 64."""
+    multiple of the 128-row wave tasks, one to many slices (H D 4 / 4 MiB rounded to eight), k on both sides of 64; with
+    k = 20 over 16 slices a row has 1-2 survivors per slice, so a batch of 64 pairs spans more activation rows than the chain
+    launch's tile holds (24) and is cut short."""
     ops = _ops()
     lib = sliced_refinement
     x = S.activations(195, B, D)
